@@ -1,0 +1,304 @@
+/*
+ * mi_pt.h — C ABI of the MI355X path-tracing integrator (libmi_pt.so).
+ *
+ * This is the drop-in boundary behind the reference renderer's `haste::Technique`
+ * interface for the PT path.  Every entry point names the reference interface it
+ * replaces (file:line relative to the reference tree).  Plain C: pointers, sizes,
+ * POD structs.  No C++ types, no torch types, never throws.
+ *
+ * Conventions shared with the reference:
+ *   - mat3 values are column-major, 9 floats: {col0.xyz, col1.xyz, col2.xyz}.
+ *   - a tangent frame is [col0 = bitangent | col1 = shading normal | col2 = tangent]
+ *     (SurfacePoint.hpp:46-50); local shading space has y = normal.
+ *   - material_id = (material_index << 2) | entity_type (SurfacePoint.hpp:8-21),
+ *     entity_type: camera 0, mesh 1, light 2, empty 3; "no hit" = UINT32_MAX.
+ *   - images are row-major [H][W][4] float, row 0 = BOTTOM of the image
+ *     (Cameras.cpp:124 maps y = 0 to view-space -1), channels = (R sum, G sum, B sum, denom).
+ */
+#ifndef MI_PT_H
+#define MI_PT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+#endif
+
+#define MI_PT_ABI_VERSION 1
+
+/* ---- error codes (reference: C++ exceptions, runtime_assert.cpp:7-11, Scene.cpp:55-57) ---- */
+enum {
+  MI_OK = 0,
+  MI_ERR_INVALID_ARGUMENT = -1, /* runtime_assert analogue: bad index / null / size mismatch        */
+  MI_ERR_NO_DEVICE = -2,        /* HIP device missing or HIP call failed (message has the detail)  */
+  MI_ERR_OUT_OF_MEMORY = -3,
+  MI_ERR_IO = -4,               /* loader.cpp:469 "Cannot load scene" analogue                      */
+  MI_ERR_UNSUPPORTED = -5,
+  MI_ERR_INTERNAL = -6
+};
+
+/* ---- entity / bsdf tags ---- */
+enum { MI_ENTITY_CAMERA = 0, MI_ENTITY_MESH = 1, MI_ENTITY_LIGHT = 2, MI_ENTITY_EMPTY = 3 };
+
+enum {
+  MI_BSDF_CAMERA = 0,       /* CameraBSDF        BSDF.cpp:195-235  (never sampled by PT)            */
+  MI_BSDF_DIFFUSE = 1,      /* DiffuseBSDF       BSDF.cpp:237-304                                  */
+  MI_BSDF_PHONG = 2,        /* PhongBSDF         BSDF.cpp:306-391                                  */
+  MI_BSDF_REFLECTION = 3,   /* ReflectionBSDF    BSDF.cpp:450-465                                  */
+  MI_BSDF_TRANSMISSION = 4, /* TransmissionBSDF  BSDF.cpp:467-504                                  */
+  MI_BSDF_LIGHT = 5,        /* LightBSDF         BSDF.cpp:73-114                                   */
+  MI_BSDF_SUN = 6           /* sun_light_bsdf    BSDF.cpp:164-193                                  */
+};
+
+/* One entry of Materials::bsdfs (Materials.hpp:14-27), flattened.  48 bytes. */
+typedef struct mi_material {
+  uint32_t type;        /* MI_BSDF_*                                                   */
+  float diffuse[3];     /* DiffuseBSDF::_diffuse / PhongBSDF::_diffuse                  */
+  float specular[3];    /* PhongBSDF::_specular                                        */
+  float power;          /* PhongBSDF::_power                                           */
+  float ior_internal;   /* TransmissionBSDF ctor arg 0 (loader.cpp:381-382)            */
+  float ior_external;   /* TransmissionBSDF ctor arg 1 (always 1.0 in the loader)      */
+  uint32_t light_id;    /* LightBSDF::_light_id / sun_light_bsdf::_light_id            */
+  uint32_t reserved;
+} mi_material;
+
+/* AreaLight (AreaLights.hpp:41-58).  80 bytes. */
+typedef struct mi_light {
+  float position[3];
+  float tangent[9];     /* column-major; col1 = emission normal (AreaLights.cpp:78-85) */
+  float size[2];
+  float exitance[3];
+  uint32_t diffuse;     /* 1 = LightBSDF (area), 0 = sun_light_bsdf (AreaLights.cpp:26-36) */
+  uint32_t material_id; /* encoded, entity_type light                                   */
+  uint32_t reserved;
+} mi_light;
+
+/* Cameras::Desc as filled by Cameras::addCameraFovX (Cameras.cpp:7-28).  40 bytes. */
+typedef struct mi_camera {
+  float position[3];
+  float direction[3];
+  float up[3];
+  float fovx;           /* radians, full horizontal angle */
+} mi_camera;
+
+/*
+ * Flattened haste::Scene (Scene.hpp:27-76): meshes (incl. the light quads the loader
+ * appends, loader.cpp:448), materials, lights, cameras.  All arrays are copied by
+ * mi_pt_create; the caller may free them afterwards.
+ *   mesh m owns triangles [mesh_tri_offset[m], mesh_tri_offset[m+1]); Embree geomID == m
+ *   (Scene.cpp:59-63); indices are GLOBAL vertex indices.
+ */
+typedef struct mi_scene_desc {
+  uint32_t n_vertices;
+  uint32_t n_triangles;
+  uint32_t n_meshes;
+  uint32_t n_materials;
+  uint32_t n_lights;
+  uint32_t n_cameras;
+  const float* positions;            /* [n_vertices][3]    Mesh::vertices (AreaLights.hpp:11-17) */
+  const float* tangents;             /* [n_vertices][9]    Mesh::tangents                        */
+  const uint32_t* indices;           /* [n_triangles][3]   Mesh::indices (+ vertex base)         */
+  const uint32_t* mesh_tri_offset;   /* [n_meshes + 1]                                           */
+  const uint32_t* mesh_material_id;  /* [n_meshes]         Mesh::material_id (encoded)           */
+  const mi_material* materials;      /* [n_materials]                                            */
+  const mi_light* lights;            /* [n_lights]                                               */
+  const mi_camera* cameras;          /* [n_cameras]                                              */
+  float bounding_sphere[4];          /* center xyz, radius (loader.cpp:408-432)                  */
+} mi_scene_desc;
+
+/* PathTracing ctor arguments (PT.cpp:5-13, make_technique.cpp:132-141, Options.hpp:30-37). */
+typedef struct mi_pt_params {
+  uint64_t max_path;   /* --max-path; UINT64_MAX / PTRDIFF_MAX = unlimited (roulette-terminated) */
+  float beta;          /* --beta      default 1.0                                              */
+  float roulette;      /* --roulette  default 0.9                                              */
+  float lights;        /* --no-lights => 0, default 1.0                                        */
+  uint32_t min_subpath;/* PT.hpp:24, always 3 in the reference                                 */
+} mi_pt_params;
+
+/* subimage_view_t window (ImageView.hpp:10-67): pixels [x0, x0+w) x [y0, y0+h). w == 0 => full image. */
+typedef struct mi_window {
+  uint32_t x0, y0, w, h;
+} mi_window;
+
+/* What Technique::render needs to fill statistics_t (Technique.cpp:55-67). */
+typedef struct mi_pt_stats {
+  uint64_t num_paths;        /* camera samples started (pixels in window * spp)                 */
+  uint64_t num_basic_rays;   /* closest-hit rays  == Scene::_numIntersectRays delta (Scene.cpp:200) */
+  uint64_t num_shadow_rays;  /* any-hit rays      == Scene::_numOccludedRays delta  (Scene.cpp:177) */
+  uint64_t numeric_errors;   /* samples dropped as non-finite (Technique.cpp:224-230)           */
+  double gpu_ms;             /* device time of the render kernels of this call (HIP events)     */
+  double trace_ms;           /* device time of the dominant (path tracing) kernel alone         */
+} mi_pt_stats;
+
+typedef struct mi_pt_handle mi_pt_handle;
+
+/* ------------------------------------------------------------------------------------------
+ * Technique / PathTracing life cycle
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces: PathTracing::PathTracing (PT.cpp:5-13) + Scene::buildAccelStructs (Scene.cpp:68-73,
+ * Embree rtcCommit Scene.cpp:47-66).  Copies the scene to `device`, builds the LBVH there. */
+int mi_pt_create(const mi_scene_desc* scene, const mi_pt_params* params, int device,
+                 mi_pt_handle** out);
+
+/* Replaces: Technique::~Technique (Technique.cpp:13) + rtcDeleteScene. */
+void mi_pt_destroy(mi_pt_handle* h);
+
+/* Replaces: Technique::render (Technique.cpp:15-77) for `spp` consecutive frames:
+ * _trace_paths + _for_each_ray + PathTracing::_traceEye + _commit_images.
+ * Writes (not adds) per-pixel (R,G,B sums, denom) of samples
+ * [sample_offset, sample_offset + spp) into rgbn_sum ([height][width][4] floats, HOST memory,
+ * row 0 = bottom); pixels outside `win` are written as zeros.  The caller adds the result into
+ * its dvec4 view exactly like Technique.cpp:222-226.  Random streams are keyed on
+ * (seed, pixel index, sample index), so disjoint sample ranges rendered anywhere sum to the
+ * same image as one call. */
+int mi_pt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height,
+                 mi_window win, uint32_t spp, uint64_t seed, uint64_t sample_offset,
+                 float* rgbn_sum, mi_pt_stats* stats);
+
+/* Same, result left in DEVICE memory (hipMalloc'ed / torch CUDA tensor storage of
+ * height*width*4 floats) so it can go straight into an RCCL reduce — the collective
+ * counterpart of merge_exr (Options.cpp:1340-1409).  `stream` is a hipStream_t (NULL = default);
+ * the call is synchronous with respect to the host when stats != NULL. */
+int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height,
+                        mi_window win, uint32_t spp, uint64_t seed, uint64_t sample_offset,
+                        float* rgbn_sum_device, void* stream, mi_pt_stats* stats);
+
+/* Replaces: reading the message of std::logic_error / std::runtime_error thrown by the
+ * reference (runtime_assert.cpp:7-11).  Thread-local, never NULL. */
+const char* mi_pt_last_error(void);
+
+int mi_pt_abi_version(void);
+
+/* Kernel variant selection (for measurement; default MI_PT_KERNEL_AUTO). */
+enum { MI_PT_KERNEL_AUTO = 0, MI_PT_KERNEL_MEGA_LDS = 1, MI_PT_KERNEL_MEGA_GLOBAL = 2 };
+int mi_pt_set_kernel(mi_pt_handle* h, int kernel);
+int mi_pt_get_kernel(mi_pt_handle* h); /* variant AUTO resolves to for this scene */
+
+/* ------------------------------------------------------------------------------------------
+ * Scene services exposed for parity tests (each is a batched form of one Scene method)
+ * ---------------------------------------------------------------------------------------- */
+
+/* SurfacePoint (SurfacePoint.hpp:37-63), 64 bytes. */
+typedef struct mi_surface_point {
+  float position[3];
+  float gnormal[3];
+  float tangent[9];
+  uint32_t material_id;
+} mi_surface_point;
+
+/* Replaces: Scene::intersect (Scene.cpp:182-203) + Scene::querySurface (Scene.cpp:80-126),
+ * n rays at once.  origins[i] supplies position + gnormal (+ material_id, ignored);
+ * out_t[i] (optional) receives Embree's tfar, out_prim[i] (optional) the global triangle id
+ * (UINT32_MAX on a miss).  All pointers are HOST memory. */
+int mi_pt_intersect(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins,
+                    const float* directions /*[n][3]*/, mi_surface_point* out_hits,
+                    float* out_t, uint32_t* out_prim);
+
+/* Replaces: Scene::occluded (Scene.cpp:151-180): 1.0 = visible, 0.0 = blocked. */
+int mi_pt_occluded(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins,
+                   const mi_surface_point* targets, float* out_visibility);
+
+/* Replaces: Technique::_for_each_ray's shoot() + PathTracing::_traceEye (Technique.cpp:321-338,
+ * PT.cpp:15-98) for an explicit list of (pixel x, pixel y, sample index): per-path radiance
+ * (float[n][3]) and per-path ray counts (uint32[n][2] = basic, shadow; optional). */
+int mi_pt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height,
+                      uint32_t n, const uint32_t* pixel_xy /*[n][2]*/,
+                      const uint64_t* sample_index /*[n]*/, uint64_t seed,
+                      float* out_radiance, uint32_t* out_ray_counts);
+
+/* ------------------------------------------------------------------------------------------
+ * LBVH (replaces Embree's rtcCommit, Scene.cpp:52-65) — download for parity tests
+ * ---------------------------------------------------------------------------------------- */
+
+/* 64-byte BVH2 node: child boxes + links.  link >= 0: internal node index; link < 0: leaf,
+ * ~link = position in the Morton-sorted triangle order. */
+typedef struct mi_bvh_node {
+  float lo0[3]; int32_t link0;
+  float hi0[3]; int32_t link1;
+  float lo1[3]; uint32_t parent;
+  float hi1[3]; uint32_t reserved;
+} mi_bvh_node;
+
+typedef struct mi_bvh_info {
+  uint32_t n_triangles;
+  uint32_t n_nodes;      /* n_triangles - 1 internal nodes (0 when n_triangles == 1)   */
+  uint32_t max_depth;    /* longest root-to-leaf path in nodes                          */
+  uint32_t stack_entries;/* traversal stack capacity the kernels were sized with        */
+  float scene_lo[3], scene_hi[3];
+  double build_ms;       /* device time of the build kernels                            */
+} mi_bvh_info;
+
+int mi_pt_bvh_info(mi_pt_handle* h, mi_bvh_info* out);
+/* nodes: [n_nodes]; sorted_tri: [n_triangles] global triangle id at each sorted position;
+ * morton: [n_triangles] 30-bit codes in sorted order.  Any pointer may be NULL. */
+int mi_pt_bvh_download(mi_pt_handle* h, mi_bvh_node* nodes, uint32_t* sorted_tri,
+                       uint32_t* morton);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side camera helpers (Cameras.cpp) — exported so tests can pin them against the
+ * reference's own camera tests (unit_tests/Cameras.test.cpp:22-44, Cameras.cpp:164-189).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi_camera_frame {
+  float view_to_world[9];  /* Cameras::view_to_world_mat3 (Cameras.cpp:104-106)  */
+  float world_to_view[9];  /* Cameras::world_to_view_mat3 (Cameras.cpp:108-110)  */
+  float position[3];
+  float focal_length_y;    /* Cameras::focal_length_y (Cameras.cpp:112-116)      */
+  float fovy;              /* Cameras::fovy (Cameras.cpp:81-88)                  */
+} mi_camera_frame;
+
+int mi_camera_setup(const mi_camera* cam, float aspect, mi_camera_frame* out);
+/* ray_direction (Cameras.cpp:120-127), view space. */
+void mi_camera_ray_direction(float px, float py, float res_x, float res_y, float focal_length_y,
+                             float out_dir[3]);
+/* pixel_position (Cameras.cpp:134-144). */
+void mi_camera_pixel_position(const float dir[3], float res_x, float res_y, float focal_length_y,
+                              float out_xy[2]);
+
+/* ------------------------------------------------------------------------------------------
+ * Scene files: own .blend reader (replaces loadScene, loader.cpp:458-487, whose assimp fork is
+ * not available) and a flat binary scene container (.miscene) so scenes travel without the
+ * reference tree.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi_blend_options {
+  float diffuse_scale_by_ref;  /* 1 => diffuse colour *= Material.ref   (fork behaviour unpinned) */
+  float specular_scale_by_spec;/* 1 => specular colour *= Material.spec                            */
+  float lamp_energy_scale;     /* exitance = rgb * energy * scale (default 1)                      */
+  uint32_t reserved;
+} mi_blend_options;
+
+typedef struct mi_scene mi_scene; /* owning container around a mi_scene_desc */
+
+int mi_scene_load_blend(const char* path, const mi_blend_options* opts, mi_scene** out);
+int mi_scene_load(const char* path, mi_scene** out);           /* .miscene */
+int mi_scene_save(const mi_scene* scene, const char* path);    /* .miscene */
+int mi_scene_from_desc(const mi_scene_desc* desc, mi_scene** out); /* deep copy */
+const mi_scene_desc* mi_scene_get_desc(const mi_scene* scene);
+const char* mi_scene_material_name(const mi_scene* scene, uint32_t i);
+const char* mi_scene_mesh_name(const mi_scene* scene, uint32_t i);
+void mi_scene_free(mi_scene* scene);
+
+/* ------------------------------------------------------------------------------------------
+ * EXR output in the reference's layout (replaces save_exr / load_exr, exr.cpp:177-232,245-297):
+ * float channels R,G,B,denom, rows flipped (exr.cpp:207-214), metadata as string attributes.
+ * ---------------------------------------------------------------------------------------- */
+int mi_exr_save_rgbn(const char* path, uint32_t width, uint32_t height, const float* rgbn,
+                     uint32_t n_meta, const char* const* meta_keys, const char* const* meta_values);
+int mi_exr_load_rgbn(const char* path, uint32_t* width, uint32_t* height, float** rgbn /* free with mi_free */);
+void mi_free(void* p);
+
+/* rms_abs_errors (ImageView.cpp:60-85): image = rgbn sums ([h][w][4]), reference = [h][w][3]. */
+int mi_rms_abs_errors(const float* rgbn, const float* reference_rgb, uint32_t width,
+                      uint32_t height, float* rms, float* abs_err);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_PT_H */

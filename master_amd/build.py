@@ -1,0 +1,81 @@
+"""Builds libmi_pt.so (HIP kernels + C-ABI host code) for gfx950 with hipcc, in-tree.
+
+The library is the product: there is no CPU fallback and no JIT cache.  Flags:
+  -ffp-contract=off   fusion happens only where the sources spell fmaf() (arithmetic contract)
+  -munsafe-fp-atomics LDS FP64 accumulation compiles to ds_add_f64, not a CAS loop
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmi_pt.so")
+
+SOURCES = [
+    "mi_pt_api.hip",
+    "device/pt_kernels.hip",
+    "device/lbvh_build.hip",
+    "scene_host.cpp",
+    "blend_reader.cpp",
+    "exr_io.cpp",
+]
+
+HEADERS = [
+    "../../include/mi_pt.h", "scene_host.hpp", "device/layout.h", "device/launch.h", "device/pt_device.h",
+    "device/rng.h", "device/vecmath.h",
+]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace("/", "_") + ".o")
+        cmd = [hipcc()] + common
+        if src.endswith(".hip"):
+            cmd += ["--offload-arch=gfx950", "-munsafe-fp-atomics"]
+        else:
+            cmd += ["-x", "c++"]
+        cmd += list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,61 @@
+// layout.h — device-side data layout shared by the host API and the kernels.
+//
+// One contiguous "scene blob" of float4 records lives in HBM (and, for scenes that fit, is
+// staged whole into LDS by every workgroup):
+//   nodes      n_nodes  x 4 float4   BVH2 node = two child boxes + two links (mi_bvh_node, 64 B)
+//   tri_isect  n_tris   x 3 float4   Morton order: v0, e1 = v0-v1, e2 = v2-v0, id, mask (48 B)
+//   tri_shade  n_tris   x 7 float4   Morton order: 3 vertex frames (3 x mat3) + material_id (112 B)
+//   materials  n_mats   x 3 float4   mi_material with `reserved` = Phong diffuse probability
+//   lights     n_lights x 6 float4   DevLight
+//   light_cdf  ceil((n_lights+1)/4) float4
+// Traversal only ever touches nodes + tri_isect; shading data is a separate stream so it
+// does not compete for cache lines with the intersection data.
+#pragma once
+#include <stdint.h>
+
+namespace mi {
+
+struct SceneView {
+  const float4* blob;  // HBM
+  uint32_t off_nodes, off_tris, off_shade, off_mats, off_lights, off_cdf;  // in float4 units
+  uint32_t blob_f4;                                                        // total float4 count
+  uint32_t n_tris, n_nodes, n_mats, n_lights;
+};
+
+struct DevLight {  // 6 float4
+  float position[3]; float weight;       // AreaLights::_weights[i] (AreaLights.cpp:199-209)
+  float t0[3]; float area;               // tangent[0]; size.x * size.y
+  float t1[3]; float size_x;             // tangent[1] = emission normal
+  float t2[3]; float size_y;             // tangent[2]
+  float radiance[3]; uint32_t material_id;  // exitance / pi (AreaLights.hpp:54)
+  float lsdf_density;                    // weight / area        (AreaLights.cpp:152)
+  float area_density;                    // 1 / area             (AreaLights.cpp:135)
+  uint32_t diffuse; uint32_t pad;
+};
+
+struct RenderParams {
+  SceneView sv;
+  // render_context_t (Technique.hpp:14-27)
+  float v2w[9];
+  float cam_pos[3];
+  float focal_length_y;
+  float res_x, res_y, res_y_inv;
+  uint32_t width, height;
+  uint32_t win_x0, win_y0, win_w, win_h;
+  uint32_t tiles_x, tiles_y;
+  uint32_t stack_entries;  // per-lane traversal stack capacity (LDS), >= BVH depth
+  // sample range
+  uint32_t spp, n_chunks, chunk_spp;
+  uint64_t seed, sample_offset;
+  // PathTracing members (PT.hpp:24-28)
+  uint32_t max_path, min_subpath;
+  float beta, roulette, lights;
+  // outputs
+  double* partial;        // [n_chunks][height*width][4] (r, g, b sums, count)
+  unsigned long long* counters;  // [4]: basic rays, shadow rays, numeric errors, paths
+  // list mode (mi_pt_trace_paths)
+  const uint32_t* list_xy; const uint64_t* list_sample; uint32_t list_n;
+  float* list_radiance; uint32_t* list_counts;
+};
+
+}  // namespace mi

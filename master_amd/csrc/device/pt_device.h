@@ -1,0 +1,339 @@
+// pt_device.h — device functions of the PT hot path (gfx950): BVH traversal, surface query,
+// BSDFs, light sampling, next-event estimation.  Every function names the reference code it
+// computes; the expression structure follows DESIGN.md's arithmetic contract.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../../include/mi_pt.h"
+#include "layout.h"
+#include "rng.h"
+#include "vecmath.h"
+
+namespace mi {
+
+constexpr int kBlock = 256;  // threads per workgroup = 4 waves
+
+struct Hit { float t, u, v; uint32_t id, pos; };  // id = global triangle index, pos = Morton position
+
+// SurfacePoint (SurfacePoint.hpp:37-63)
+struct Surf { f3 position, gnormal; m33 tangent; uint32_t material_id; };
+
+MI_DEV bool surf_is_light(const Surf& s) { return (s.material_id & 3u) == MI_ENTITY_LIGHT; }
+MI_DEV f3 to_world(const Surf& s, f3 v) { return mulmv(s.tangent, v); }
+MI_DEV f3 to_surface(const Surf& s, f3 v) { return mulvm(v, s.tangent); }
+MI_DEV f3 xyz(float4 v) { return F3(v.x, v.y, v.z); }
+
+// ---------------------------------------------------------------------------------------------
+// Ray / triangle: Embree 2 single-ray Moeller–Trumbore (rtcIntersect / rtcOccluded at
+// Scene.cpp:175,198), mask test of Scene.cpp:42.  ANY = rtcOccluded (t in (0, h.t]).
+// Closest-hit ties: smaller t, then smaller global triangle id (order independent).
+template <bool ANY>
+MI_DEV bool tri_test(const float4* __restrict__ tris, uint32_t pos, f3 org, f3 dir, uint32_t ray_mask, Hit& h) {
+  const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
+  const uint32_t mask = __float_as_uint(c.z);
+  if (!(mask & ray_mask)) return false;
+  const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
+  const uint32_t id = __float_as_uint(c.y);
+  const f3 ng = cross(e2, e1);
+  const f3 C = v0 - org;
+  const f3 R = cross(C, dir);
+  const float den = dot(ng, dir);
+  const float absden = fabsf(den);
+  const float sgn = den < 0.0f ? -1.0f : 1.0f;
+  const float U = dot(R, e2) * sgn;
+  const float V = dot(R, e1) * sgn;
+  if (den == 0.0f) return false;
+  if (!(U >= 0.0f) || !(V >= 0.0f) || !(U + V <= absden)) return false;
+  const float T = dot(ng, C) * sgn;
+  if (!(absden * 0.0f < T)) return false;
+  const float t = T / absden;
+  if (ANY) {
+    if (t <= h.t) { h.id = id; return true; }
+    return false;
+  }
+  if (t < h.t || (t == h.t && id < h.id)) {
+    h.t = t; h.u = U / absden; h.v = V / absden; h.id = id; h.pos = pos;
+    return true;
+  }
+  return false;
+}
+
+MI_DEV bool box_test(f3 lo, f3 hi, f3 org, f3 inv, float tmax, float& tnear) {
+  const float t0x = (lo.x - org.x) * inv.x, t1x = (hi.x - org.x) * inv.x;
+  const float t0y = (lo.y - org.y) * inv.y, t1y = (hi.y - org.y) * inv.y;
+  const float t0z = (lo.z - org.z) * inv.z, t1z = (hi.z - org.z) * inv.z;
+  const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+  const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  tnear = tn;
+  return tn <= tf * 1.0000004f;
+}
+
+// BVH2 traversal with a per-lane stack in LDS (stack[level * kBlock + tid]: consecutive lanes
+// hit consecutive banks).  `sb` = scene blob base (LDS or HBM).
+template <bool ANY>
+MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_t* __restrict__ stack, f3 org, f3 dir,
+                     uint32_t ray_mask, Hit& h) {
+  const float4* nodes = sb + sv.off_nodes;
+  const float4* tris = sb + sv.off_tris;
+  if (sv.n_nodes == 0) {
+    tri_test<ANY>(tris, 0, org, dir, ray_mask, h);
+    return;
+  }
+  const f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  int sp = 0;
+  int node = 0;
+  for (;;) {
+    if (node >= 0) {
+      const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+      float tn0, tn1;
+      const bool h0 = box_test(xyz(n0), xyz(n1), org, inv, h.t, tn0);
+      const bool h1 = box_test(xyz(n2), xyz(n3), org, inv, h.t, tn1);
+      const int l0 = __float_as_int(n0.w), l1 = __float_as_int(n1.w);
+      if (h0 && h1) {
+        const bool sw = tn1 < tn0;
+        stack[sp * kBlock] = uint32_t(sw ? l0 : l1);
+        ++sp;
+        node = sw ? l1 : l0;
+        continue;
+      }
+      if (h0 || h1) {
+        node = h0 ? l0 : l1;
+        continue;
+      }
+    } else {
+      const bool hit = tri_test<ANY>(tris, uint32_t(~node), org, dir, ray_mask, h);
+      if (ANY && hit) return;
+    }
+    if (sp == 0) return;
+    --sp;
+    node = int(stack[sp * kBlock]);
+  }
+}
+
+// Scene::querySurface (Scene.cpp:80-126)
+MI_DEV Surf query_surface(const float4* __restrict__ sb, const SceneView& sv, f3 org, f3 dir, const Hit& h) {
+  Surf p;
+  const float4* sh = sb + sv.off_shade + 7 * h.pos;
+  const float4 q0 = sh[0], q1 = sh[1], q2 = sh[2], q3 = sh[3], q4 = sh[4], q5 = sh[5], q6 = sh[6];
+  const float w = 1.f - h.u - h.v;
+  const float u = h.u, v = h.v;
+  // vertex frames: t0 = q0.xyzw q1.xyzw q2.x ; t1 = q2.yzw q3.xyzw q4.xy ; t2 = q4.zw q5.xyzw q6.xyz
+  const f3 a0 = F3(q0.x, q0.y, q0.z), a1 = F3(q0.w, q1.x, q1.y), a2 = F3(q1.z, q1.w, q2.x);
+  const f3 b0 = F3(q2.y, q2.z, q2.w), b1 = F3(q3.x, q3.y, q3.z), b2 = F3(q3.w, q4.x, q4.y);
+  const f3 c0 = F3(q4.z, q4.w, q5.x), c1 = F3(q5.y, q5.z, q5.w), c2 = F3(q6.x, q6.y, q6.z);
+  p.material_id = __float_as_uint(q6.w);
+  p.position = madd(org, dir, h.t);
+  p.tangent.c0 = (a0 * w + b0 * u) + c0 * v;
+  p.tangent.c1 = (a1 * w + b1 * u) + c1 * v;
+  p.tangent.c2 = (a2 * w + b2 * u) + c2 * v;
+  p.tangent.c1 = normalize(p.tangent.c1);
+  p.tangent.c0 = p.tangent.c0 - p.tangent.c1 * dot(p.tangent.c0, p.tangent.c1);
+  p.tangent.c0 = normalize(p.tangent.c0);
+  p.tangent.c2 = (p.tangent.c2 - p.tangent.c1 * dot(p.tangent.c2, p.tangent.c1)) - p.tangent.c0 * dot(p.tangent.c2, p.tangent.c0);
+  p.tangent.c2 = normalize(p.tangent.c2);
+  // RayIsect::gnormal / omega (RayIsect.hpp:24-25), flip toward the ray origin (Scene.cpp:119-120)
+  const float4* tr = sb + sv.off_tris + 3 * h.pos;
+  const float4 ta = tr[0], tb = tr[1], tc = tr[2];
+  const f3 e1 = F3(ta.w, tb.x, tb.y), e2 = F3(tb.z, tb.w, tc.x);
+  const f3 g = normalize(-cross(e2, e1));
+  const f3 omega = normalize(-dir);
+  p.gnormal = g * (dot(omega, g) < 0.0f ? -1.0f : 1.0f);
+  return p;
+}
+
+// origin offset of Scene::intersect (Scene.cpp:185-188)
+MI_DEV f3 nudge(f3 position, f3 gnormal, f3 dir) {
+  return position + (gnormal * (dot(gnormal, dir) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+}
+
+// Scene::occluded (Scene.cpp:151-180): 1 = visible.
+MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, uint32_t* stack, f3 opos, f3 ognormal, f3 tpos,
+                      f3 tgnormal) {
+  const f3 direction = normalize(tpos - opos);
+  const f3 ao = opos + (ognormal * (dot(ognormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+  const f3 at = tpos + (tgnormal * (dot(tgnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+  Hit h; h.t = 1.0f; h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+  traverse<true>(sb, sv, stack, ao, at - ao, 1u << MI_ENTITY_MESH, h);
+  return h.id != 0xFFFFFFFFu ? 0.f : 1.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BSDFs
+struct BQuery { f3 throughput; float density, densityRev; int finite; };
+struct BSample { BQuery q; f3 omega; };
+
+struct Material { uint32_t type; f3 diffuse, specular; float power, ior_internal, ior_external; uint32_t light_id; float phong_pd; };
+
+MI_DEV Material load_material(const float4* __restrict__ sb, const SceneView& sv, uint32_t material_id) {
+  const float4* m = sb + sv.off_mats + 3 * (material_id >> 2);
+  const float4 a = m[0], b = m[1], c = m[2];
+  Material r;
+  r.type = __float_as_uint(a.x); r.diffuse = F3(a.y, a.z, a.w); r.specular = F3(b.x, b.y, b.z); r.power = b.w;
+  r.ior_internal = c.x; r.ior_external = c.y; r.light_id = __float_as_uint(c.z); r.phong_pd = c.w;
+  return r;
+}
+
+// DiffuseBSDF::_query (BSDF.cpp:291-304)
+MI_DEV BQuery diffuse_query_local(const Material& m, f3 gn, f3 incident, f3 outgoing) {
+  const float same_side = dot(incident, gn) * dot(outgoing, gn) > 0.0f ? 1.0f : 0.0f;
+  BQuery q;
+  q.throughput = (m.diffuse * MI_ONE_OVER_PI) * same_side;
+  q.density = fabsf(outgoing.y * MI_ONE_OVER_PI) * same_side;
+  q.densityRev = fabsf(incident.y * MI_ONE_OVER_PI) * same_side;
+  q.finite = 1;
+  return q;
+}
+// PhongBSDF::_query (BSDF.cpp:354-391)
+MI_DEV BQuery phong_query_local(const Material& m, f3 incident, f3 outgoing, float same_side) {
+  const float pd = m.phong_pd, ps = 1.0f - pd;
+  const float dd = fabsf(outgoing.y * MI_ONE_OVER_PI), ddr = fabsf(incident.y * MI_ONE_OVER_PI);
+  const f3 diffuse = m.diffuse * MI_ONE_OVER_PI;
+  const float half_over_pi = 0.5f * MI_ONE_OVER_PI;
+  const f3 reflected = F3(-incident.x, incident.y, -incident.z);
+  float ca = dot(outgoing, reflected);
+  ca = ca < 0.0f ? 0.0f : (ca > 1.0f ? 1.0f : ca);
+  const float cap = powf(ca, m.power);
+  const float sd = (m.power + 1.0f) * half_over_pi * cap;
+  const f3 specular = ((m.specular * (m.power + 2.0f)) * half_over_pi) * cap;
+  BQuery q;
+  q.density = same_side * (sd * ps + dd * pd);
+  q.densityRev = same_side * (sd * ps + ddr * pd);
+  q.throughput = (diffuse + specular) * same_side;
+  q.finite = 1;
+  return q;
+}
+MI_DEV BQuery bq_zero() { BQuery q; q.throughput = F3(0, 0, 0); q.density = 0; q.densityRev = 0; q.finite = 1; return q; }
+
+// Scene::queryBSDF(surface, incident, outgoing) (Scene.cpp:142-149) for surface materials.
+MI_DEV BQuery bsdf_query(const Material& m, const Surf& sf, f3 incident, f3 outgoing) {
+  if (m.type == MI_BSDF_DIFFUSE)  // BSDF.cpp:239-243
+    return diffuse_query_local(m, to_surface(sf, sf.gnormal), to_surface(sf, incident), to_surface(sf, outgoing));
+  if (m.type == MI_BSDF_PHONG) {  // BSDF.cpp:317-326
+    const float same_side = dot(incident, sf.gnormal) * dot(outgoing, sf.gnormal) > 0.0f ? 1.0f : 0.0f;
+    return phong_query_local(m, to_surface(sf, incident), to_surface(sf, outgoing), same_side);
+  }
+  BQuery q = bq_zero();  // DeltaBSDF::query (BSDF.cpp:438-448)
+  q.finite = 0;
+  return q;
+}
+
+// sample_lambert (Sample.inl:52-60)
+MI_DEV f3 sample_lambert(Rng& g, f3 omega) {
+  const float y = sqrtf(rng_f(g)) * gsign(omega.y);
+  const float r = sqrtf(1.0f - y * y);
+  float sn, cs;
+  sincos_2pi(rng_f(g), &sn, &cs);
+  return F3(r * cs, y, r * sn);
+}
+// reflection_to_surface (Sample.inl:43-50) + sample_phong (Sample.inl:139-151)
+MI_DEV f3 sample_phong(Rng& g, f3 omega, float power) {
+  m33 m;
+  m.c1 = F3(-omega.x, omega.y, -omega.z);
+  m.c2 = normalize(F3(0.0f, 1.0f, 0.0f) - m.c1 * m.c1.y);
+  m.c0 = normalize(cross(m.c1, m.c2));
+  const float y = powf(rng_f(g), 1.0f / (power + 1.0f));
+  const float r = sqrtf(1.0f - y * y);
+  float sn, cs;
+  sincos_2pi(rng_f(g), &sn, &cs);
+  return mulmv(m, F3(r * cs, y, r * sn));
+}
+// Scene::sampleBSDF (Scene.cpp:133-140)
+MI_DEV BSample bsdf_sample(const Material& m, Rng& g, const Surf& sf, f3 omega) {
+  BSample r;
+  r.q = bq_zero();
+  r.omega = F3(0, 0, 0);
+  const f3 lo = to_surface(sf, omega);
+  if (m.type == MI_BSDF_DIFFUSE) {  // BSDF.cpp:245-262
+    const f3 d = sample_lambert(g, lo);
+    r.q = diffuse_query_local(m, to_surface(sf, sf.gnormal), lo, d);
+    r.omega = to_world(sf, d);
+  } else if (m.type == MI_BSDF_PHONG) {  // BSDF.cpp:328-352
+    f3 d;
+    if (rng_f(g) < m.phong_pd) d = sample_lambert(g, lo); else d = sample_phong(g, lo, m.power);
+    r.omega = to_world(sf, d);
+    const float same_side = dot(omega, sf.gnormal) * dot(r.omega, sf.gnormal) > 0.0f ? 1.0f : 0.0f;
+    r.q = phong_query_local(m, lo, d, same_side);
+  } else if (m.type == MI_BSDF_REFLECTION) {  // BSDF.cpp:450-465
+    const float v = 1.0f / lo.y;
+    r.q.throughput = F3(v, v, v);
+    r.omega = to_world(sf, F3(-lo.x, lo.y, -lo.z));
+    r.q.density = 1.0f; r.q.densityRev = 1.0f; r.q.finite = 0;
+  } else if (m.type == MI_BSDF_TRANSMISSION) {  // BSDF.cpp:467-504
+    const float ext_over_int = m.ior_external / m.ior_internal;
+    f3 o;
+    if (lo.y > 0.f) {
+      const float eta = ext_over_int;
+      const float yy = sqrtf(1 - eta * eta * (1 - lo.y * lo.y));
+      o = ((lo - F3(0.0f, lo.y, 0.0f)) * -eta) - F3(0.0f, yy, 0.0f);
+    } else {
+      const float eta = 1.0f / ext_over_int;
+      const float yy = sqrtf(1 - eta * eta * (1 - lo.y * lo.y));
+      o = ((lo - F3(0.0f, lo.y, 0.0f)) * -eta) + F3(0.0f, yy, 0.0f);
+    }
+    const float v = 1.0f / fabsf(o.y);
+    r.q.throughput = F3(v, v, v);
+    r.omega = to_world(sf, o);
+    r.q.density = 1.0f; r.q.densityRev = 1.0f; r.q.finite = 0;
+  } else {  // light / camera materials are never sampled by PT (lights are passed through)
+    r.omega = -omega; r.q.density = 1.0f;
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lights
+MI_DEV const float4* light_rec(const float4* __restrict__ sb, const SceneView& sv, uint32_t id) { return sb + sv.off_lights + 6 * id; }
+
+// Scene::queryLSDF -> AreaLights::queryLSDF (Scene.cpp:128-131, AreaLights.cpp:142-155)
+MI_DEV void query_lsdf(const float4* __restrict__ sb, const SceneView& sv, uint32_t light_id, f3 omega, f3& radiance, float& density) {
+  const float4* L = light_rec(sb, sv, light_id);
+  const float4 l2 = L[2], l4 = L[4], l5 = L[5];
+  const float c = dot(omega, xyz(l2));
+  radiance = xyz(l4) * (c > 0.0f ? 1.0f : 0.0f);
+  density = l5.x;
+}
+
+MI_DEV float powb(float x, float beta) { return beta == 1.0f ? x : (beta == 2.0f ? x * x : powf(x, beta)); }
+
+// PathTracing::_connect (PT.cpp:100-120) incl. AreaLights::sample (AreaLights.cpp:121-140,216-231),
+// LightBSDF::query / sun_light_bsdf::query (BSDF.cpp:95-114,181-191; only .throughput is used),
+// Edge (SurfacePoint.hpp:65-83) and the shadow ray.
+MI_DEV f3 connect(const float4* __restrict__ sb, const SceneView& sv, uint32_t* stack, Rng& g, const Material& mat,
+                  const Surf& x, f3 x_omega, f3 x_throughput, float beta, uint32_t& n_shadow) {
+  const float u = rng_f(g);
+  const float* cdf = reinterpret_cast<const float*>(sb + sv.off_cdf);
+  uint32_t id = sv.n_lights - 1;
+  for (uint32_t i = 0; i + 1 < sv.n_lights; ++i) {
+    if (u < cdf[i + 1]) { id = i; break; }
+  }
+  const float4* L = light_rec(sb, sv, id);
+  const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4], l5 = L[5];
+  const float sx = rng_f(g), sy = rng_f(g);
+  const float ux = (sx - 0.5f) * l2.w, uy = (sy - 0.5f) * l3.w;
+  const f3 lpos = (xyz(l0) + xyz(l1) * ux) + xyz(l3) * uy;
+  const f3 lnormal = xyz(l2);
+  const f3 omega = normalize(x.position - lpos);
+  // light-side "BSDF": front side only; sun lights contribute nothing through NEE
+  const float front = (__float_as_uint(l5.z) != 0u && dot(lnormal, omega) > 0.0f) ? 1.0f : 0.0f;
+  if (front * 3.0f < MI_FLT_EPSILON) return F3(0, 0, 0);
+  const BQuery eb = bsdf_query(mat, x, -omega, x_omega);
+  // Edge(light.surface, eye.surface, omega)
+  const f3 d = lpos - x.position;
+  const float distSqInv = 1.0f / dot(d, d);
+  const float fCos = fabsf(dot(omega, x.tangent.c1));
+  const float bCos = fabsf(dot(omega, lnormal));
+  const float fG = distSqInv * fCos;
+  const float bG = distSqInv * bCos;
+  const float cd = l5.y * l0.w;  // area_density * light_density
+  const float wInv = powb(eb.densityRev * bG, beta) / powb(cd, beta) + 1.0f;
+  const float occ = occluded(sb, sv, stack, x.position, x.gnormal, lpos, lnormal);
+  ++n_shadow;
+  f3 r = (xyz(l4) * occ) / cd;
+  r = r * x_throughput;
+  r = r * eb.throughput;
+  r = r * bCos;
+  r = r * fG;
+  return r / wInv;
+}
+
+}  // namespace mi

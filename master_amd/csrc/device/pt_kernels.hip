@@ -1,0 +1,365 @@
+// pt_kernels.hip — the path-tracing megakernel for gfx950 and its satellites.
+//
+// pt_megakernel<LDS_SCENE, LIST>: one wave owns an 8x8 pixel tile x a chunk of samples =
+// a pool of 64 * chunk_spp camera samples.  Every lane runs the PT state machine
+// (PathTracing::_traceEye, PT.cpp:15-98) one path SEGMENT per loop trip: one closest-hit
+// traversal, then — if the hit is a surface vertex — next-event estimation with its shadow
+// ray, BSDF sampling and Russian roulette.  A lane whose path ends pulls the next sample of
+// the pool at once (wave ballot + prefix count), so the wave stays full until the pool is
+// drained; per-pixel sums live in LDS as FP64 (Technique.cpp:338) and leave the wave once.
+//
+//   LDS_SCENE  the whole scene blob (BVH nodes, triangles, frames, materials, lights) is
+//              staged into LDS by the workgroup; otherwise it is read from HBM/L2.
+//   LIST       mi_pt_trace_paths: samples come from an explicit (pixel, sample) list and
+//              per-path radiance is written out — same state machine, same code.
+//
+// LDS: [scene blob (LDS_SCENE)] [traversal stacks: stack_entries x 256 dwords] [4 x per-wave
+// pixel accumulators: 3 x 64 doubles + 64 counts].
+#include <hip/hip_runtime.h>
+
+#include "pt_device.h"
+
+namespace mi {
+
+MI_DEV uint32_t rank_in(uint64_t mask) {  // number of set bits of `mask` below this lane
+  return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+MI_DEV uint32_t wave_sum(uint32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4;
+
+template <bool LDS_SCENE, bool LIST>
+__global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
+  extern __shared__ float4 smem[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  const SceneView sv = p.sv;
+
+  const uint32_t blob_f4 = LDS_SCENE ? sv.blob_f4 : 0u;
+  const float4* sb = sv.blob;
+  if (LDS_SCENE) {
+    for (uint32_t i = tid; i < blob_f4; i += kBlock) smem[i] = sv.blob[i];
+    sb = smem;
+  }
+  uint32_t* stack = reinterpret_cast<uint32_t*>(smem + blob_f4) + tid;
+  char* acc_base = reinterpret_cast<char*>(smem + blob_f4) + size_t(p.stack_entries) * kBlock * 4 + size_t(wave) * kAccBytesPerWave;
+  double* acc_r = reinterpret_cast<double*>(acc_base);
+  double* acc_g = acc_r + 64;
+  double* acc_b = acc_g + 64;
+  uint32_t* acc_n = reinterpret_cast<uint32_t*>(acc_b + 64);
+  if (!LIST) { acc_r[lane] = 0.0; acc_g[lane] = 0.0; acc_b[lane] = 0.0; acc_n[lane] = 0u; }
+  __syncthreads();
+
+  // ---- which pool does this wave own?  XCD-aware: workgroups are dealt round-robin over the 8
+  // XCDs (b % 8), so give each XCD a contiguous range of logical work and with it a contiguous
+  // screen region (its L2 then sees one part of the BVH).  Speed only, never correctness.
+  const uint32_t nb = gridDim.x, b = blockIdx.x;
+  const uint32_t q = nb >> 3, rr = nb & 7u, xcd = b & 7u, slot = b >> 3;
+  const uint32_t logical_block = xcd * q + (xcd < rr ? xcd : rr) + slot;
+  const uint32_t logical_wave = logical_block * 4u + wave;
+
+  uint32_t pool_next, pool_end, tile_x0 = 0, tile_y0 = 0, chunk = 0;
+  uint64_t chunk_sample0 = 0;
+  if (LIST) {
+    const uint32_t per_wave = 64u * 16u;
+    pool_next = logical_wave * per_wave;
+    pool_end = pool_next + per_wave < p.list_n ? pool_next + per_wave : p.list_n;
+    if (pool_next > pool_end) pool_next = pool_end;
+  } else {
+    const uint32_t n_tiles = p.tiles_x * p.tiles_y;
+    const uint32_t tile = logical_wave / p.n_chunks;
+    chunk = logical_wave - tile * p.n_chunks;
+    const bool valid = tile < n_tiles;
+    const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    tile_x0 = p.win_x0 + tx * 8u;
+    tile_y0 = p.win_y0 + ty * 8u;
+    const uint32_t s0 = chunk * p.chunk_spp;
+    const uint32_t s1 = s0 + p.chunk_spp < p.spp ? s0 + p.chunk_spp : p.spp;
+    chunk_sample0 = p.sample_offset + s0;
+    pool_next = 0;
+    pool_end = (valid && s1 > s0) ? (s1 - s0) * 64u : 0u;
+  }
+
+  const m33 v2w = {F3(p.v2w[0], p.v2w[1], p.v2w[2]), F3(p.v2w[3], p.v2w[4], p.v2w[5]), F3(p.v2w[6], p.v2w[7], p.v2w[8])};
+  const f3 cam_pos = F3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+  const f3 cam_gnormal = -v2w.c2;  // Technique::_camera_surface (Technique.cpp:107-116)
+
+  // ---- per-lane path state ----
+  bool alive = false;
+  uint32_t mode = 0;  // 0 = before the first surface vertex (PT.cpp:20-26), 1 = after a BSDF sample (PT.cpp:46-82)
+  f3 org = F3(0, 0, 0), dir = F3(0, 0, 1);
+  f3 xpos = F3(0, 0, 0);   // eye[prv].surface.position
+  f3 tnum = F3(0, 0, 0);   // eye[prv].throughput * bsdf.throughput * edge.bCosTheta (PT.cpp:59-60)
+  float bs_density = 1.0f; // bsdf.density
+  int bs_finite = 1;       // bsdf.finite
+  f3 radiance = F3(0, 0, 0);
+  uint32_t path_size = 0;
+  Rng rng; rng.state = 0;
+  uint32_t pix = 0, item_id = 0;
+  uint32_t n_basic = 0, n_shadow = 0, n_err = 0, n_paths = 0;
+  uint32_t path_basic = 0, path_shadow = 0;  // LIST mode per-path counts
+
+  for (;;) {
+    // ---- path regeneration: dead lanes take the next samples of the wave's pool ----
+    {
+      const bool need = !alive;
+      const uint64_t m = __ballot(need);
+      if (m != 0ull && pool_next < pool_end) {
+        const uint32_t item = pool_next + rank_in(m);
+        pool_next += uint32_t(__popcll(m));
+        if (need && item < pool_end) {
+          uint32_t px, py; uint64_t sample; bool ok = true;
+          if (LIST) {
+            px = p.list_xy[2 * item]; py = p.list_xy[2 * item + 1]; sample = p.list_sample[item];
+            item_id = item;
+          } else {
+            pix = item & 63u;
+            px = tile_x0 + (pix & 7u); py = tile_y0 + (pix >> 3);
+            sample = chunk_sample0 + (item >> 6);
+            ok = px < p.win_x0 + p.win_w && py < p.win_y0 + p.win_h;
+          }
+          if (ok) {
+            // shoot() (Technique.cpp:321-331) + ray_direction (Cameras.cpp:120-127)
+            rng = rng_seed(p.seed, py * p.width + px, sample);
+            const float u0 = rng_f(rng), u1 = rng_f(rng);
+            const float fx = float(px) + u0, fy = float(py) + u1;
+            const float vx = fx * p.res_y_inv * 2.0f - p.res_x * p.res_y_inv;
+            const float vy = fy * p.res_y_inv * 2.0f - 1.0f;
+            dir = mulmv(v2w, normalize(F3(vx, vy, -p.focal_length_y)));
+            org = nudge(cam_pos, cam_gnormal, dir);
+            mode = 0; radiance = F3(0, 0, 0); path_size = 0; alive = true;
+            path_basic = 0; path_shadow = 0;
+            ++n_paths;
+          }
+        }
+      }
+    }
+    if (__ballot(alive) == 0ull) {
+      if (pool_next >= pool_end) break;
+      continue;
+    }
+
+    if (alive) {
+      // ---- Scene::intersect (Scene.cpp:182-203) ----
+      Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+      traverse<false>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h);
+      ++n_basic; ++path_basic;
+
+      bool terminate = false, do_vertex = false;
+      Surf sp;
+      f3 x_throughput = F3(1, 1, 1);
+      if (h.id == 0xFFFFFFFFu) {
+        terminate = true;  // PT.cpp:28,49-51: a miss ends the path (PT ignores the sky)
+      } else {
+        sp = query_surface(sb, sv, org, dir, h);
+        const bool is_light = surf_is_light(sp);
+        if (mode == 0u) {
+          if (is_light && p.max_path > 0u) {  // PT.cpp:23-26: directly visible light, continue through it
+            const Material lm = load_material(sb, sv, sp.material_id);
+            f3 le; float dens;
+            query_lsdf(sb, sv, lm.light_id, -dir, le, dens);
+            radiance = radiance + le * p.lights;
+            org = nudge(sp.position, sp.gnormal, dir);
+          } else if (p.max_path < 2u) {
+            terminate = true;  // PT.cpp:28-30
+          } else {
+            path_size = 2; do_vertex = true;  // PT.cpp:32-38
+          }
+        } else {
+          // new vertex z = hit (PT.cpp:53-68); Edge(eye[prv], eye[itr], -dir)
+          const f3 omega = -dir;
+          const f3 d = xpos - sp.position;
+          const float distSqInv = 1.0f / dot(d, d);
+          const float fCos = fabsf(dot(omega, sp.tangent.c1));
+          const float fG = distSqInv * fCos;
+          if (l1norm(tnum) < MI_FLT_EPSILON) {
+            terminate = true;  // PT.cpp:62-64
+          } else {
+            const f3 ztp = tnum / bs_density;  // PT.cpp:66
+            if (is_light) {  // PT.cpp:70-79: MIS-weighted emission, then continue through the light
+              const Material lm = load_material(sb, sv, sp.material_id);
+              f3 le; float dens;
+              query_lsdf(sb, sv, lm.light_id, omega, le, dens);
+              float wInv = powb(dens, p.beta) / powb(fG * bs_density, p.beta) + 1.0f;
+              if (bs_finite == 0) wInv = 1.0f;
+              radiance = radiance + (le * ztp) / wInv;
+              org = nudge(sp.position, sp.gnormal, dir);
+            } else {
+              // Russian roulette (PT.cpp:86-94)
+              const float roul = path_size < p.min_subpath ? 1.0f : p.roulette;
+              const float uu = rng_f(rng);
+              if (roul < uu) {
+                terminate = true;
+              } else {
+                x_throughput = ztp / roul;
+                ++path_size;
+                if (path_size > p.max_path) terminate = true; else do_vertex = true;  // PT.cpp:40
+              }
+            }
+          }
+        }
+      }
+
+      if (do_vertex) {
+        // ---- vertex x = sp: NEE (PT.cpp:41) then BSDF sample (PT.cpp:43-44) ----
+        const Material mat = load_material(sb, sv, sp.material_id);
+        const f3 x_omega = -dir;
+        uint32_t ns = 0;
+        radiance = radiance + connect(sb, sv, stack, rng, mat, sp, x_omega, x_throughput, p.beta, ns);
+        n_shadow += ns; path_shadow += ns;
+        const BSample bs = bsdf_sample(mat, rng, sp, x_omega);
+        const float bCos = fabsf(dot(-bs.omega, sp.tangent.c1));  // Edge::bCosTheta with omega = -bsdf.omega
+        tnum = (x_throughput * bs.q.throughput) * bCos;
+        bs_density = bs.q.density; bs_finite = bs.q.finite;
+        xpos = sp.position;
+        dir = bs.omega;
+        org = nudge(sp.position, sp.gnormal, dir);
+        mode = 1u;
+      }
+
+      if (terminate) {
+        // ---- _eye_image += radiance; finite filter of _commit_images (Technique.cpp:222-230,338) ----
+        alive = false;
+        if (LIST) {
+          p.list_radiance[3 * item_id] = radiance.x; p.list_radiance[3 * item_id + 1] = radiance.y; p.list_radiance[3 * item_id + 2] = radiance.z;
+          if (p.list_counts) { p.list_counts[2 * item_id] = path_basic; p.list_counts[2 * item_id + 1] = path_shadow; }
+        } else if (isfinite(l1norm(radiance))) {
+          atomicAdd(&acc_r[pix], double(radiance.x));
+          atomicAdd(&acc_g[pix], double(radiance.y));
+          atomicAdd(&acc_b[pix], double(radiance.z));
+          atomicAdd(&acc_n[pix], 1u);
+        } else {
+          ++n_err;
+        }
+      }
+    }
+  }
+
+  // ---- the wave's sums leave LDS once: partial[chunk][pixel] = (r, g, b, count) ----
+  if (!LIST && pool_end != 0u) {
+    const uint32_t px = tile_x0 + (lane & 7u), py = tile_y0 + (lane >> 3);
+    if (px < p.win_x0 + p.win_w && py < p.win_y0 + p.win_h) {
+      double* o = p.partial + (size_t(chunk) * p.width * p.height + size_t(py) * p.width + px) * 4;
+      reinterpret_cast<double2*>(o)[0] = make_double2(acc_r[lane], acc_g[lane]);
+      reinterpret_cast<double2*>(o)[1] = make_double2(acc_b[lane], double(acc_n[lane]));
+    }
+  }
+  const uint32_t sb_ = wave_sum(n_basic), ss_ = wave_sum(n_shadow), se_ = wave_sum(n_err), sp_ = wave_sum(n_paths);
+  if (lane == 0 && p.counters) {
+    if (sb_) atomicAdd(&p.counters[0], (unsigned long long)sb_);
+    if (ss_) atomicAdd(&p.counters[1], (unsigned long long)ss_);
+    if (se_) atomicAdd(&p.counters[2], (unsigned long long)se_);
+    if (sp_) atomicAdd(&p.counters[3], (unsigned long long)sp_);
+  }
+}
+
+// rgbn[pixel] = sum over chunks (fixed order) of the FP64 partials, cast to FP32 — the
+// payload handed to the caller / to the RCCL reduce ([H][W][4], row 0 = bottom).
+__global__ __launch_bounds__(256) void pt_finalize(const double* __restrict__ partial, float4* __restrict__ rgbn, uint32_t width,
+                                                  uint32_t height, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                                  uint32_t n_chunks) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= width * height) return;
+  const uint32_t y = i / width, x = i - y * width;
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (x >= x0 && x < x0 + w && y >= y0 && y < y0 + h) {
+    double r = 0.0, g = 0.0, b = 0.0, n = 0.0;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      const double2* s = reinterpret_cast<const double2*>(partial + (size_t(c) * width * height + i) * 4);
+      const double2 a = s[0], bb = s[1];
+      r += a.x; g += a.y; b += bb.x; n += bb.y;
+    }
+    out = make_float4(float(r), float(g), float(b), float(n));
+  }
+  rgbn[i] = out;
+}
+
+// Batched Scene::intersect + querySurface (parity hook, mi_pt_intersect).
+__global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t n, const mi_surface_point* __restrict__ origins,
+                                                     const float* __restrict__ dirs, mi_surface_point* __restrict__ out_hits,
+                                                     float* __restrict__ out_t, uint32_t* __restrict__ out_prim) {
+  extern __shared__ float4 smem[];
+  uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const f3 pos = F3(origins[i].position[0], origins[i].position[1], origins[i].position[2]);
+  const f3 gn = F3(origins[i].gnormal[0], origins[i].gnormal[1], origins[i].gnormal[2]);
+  const f3 dir = F3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+  const f3 org = nudge(pos, gn, dir);
+  Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+  traverse<false>(sv.blob, sv, stack, org, dir, 0xFFFFFFFFu, h);
+  if (out_t) out_t[i] = h.t;
+  if (out_prim) out_prim[i] = h.id;
+  if (out_hits) {
+    mi_surface_point o;
+    if (h.id == 0xFFFFFFFFu) {
+      for (int k = 0; k < 3; ++k) { o.position[k] = 0; o.gnormal[k] = 0; }
+      for (int k = 0; k < 9; ++k) o.tangent[k] = 0;
+      o.material_id = 0xFFFFFFFFu;
+    } else {
+      const Surf s = query_surface(sv.blob, sv, org, dir, h);
+      o.position[0] = s.position.x; o.position[1] = s.position.y; o.position[2] = s.position.z;
+      o.gnormal[0] = s.gnormal.x; o.gnormal[1] = s.gnormal.y; o.gnormal[2] = s.gnormal.z;
+      o.tangent[0] = s.tangent.c0.x; o.tangent[1] = s.tangent.c0.y; o.tangent[2] = s.tangent.c0.z;
+      o.tangent[3] = s.tangent.c1.x; o.tangent[4] = s.tangent.c1.y; o.tangent[5] = s.tangent.c1.z;
+      o.tangent[6] = s.tangent.c2.x; o.tangent[7] = s.tangent.c2.y; o.tangent[8] = s.tangent.c2.z;
+      o.material_id = s.material_id;
+    }
+    out_hits[i] = o;
+  }
+}
+
+// Batched Scene::occluded (parity hook, mi_pt_occluded).
+__global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t n, const mi_surface_point* __restrict__ a,
+                                                    const mi_surface_point* __restrict__ b, float* __restrict__ out) {
+  extern __shared__ float4 smem[];
+  uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  out[i] = occluded(sv.blob, sv, stack, F3(a[i].position[0], a[i].position[1], a[i].position[2]),
+                    F3(a[i].gnormal[0], a[i].gnormal[1], a[i].gnormal[2]), F3(b[i].position[0], b[i].position[1], b[i].position[2]),
+                    F3(b[i].gnormal[0], b[i].gnormal[1], b[i].gnormal[2]));
+}
+
+// ---- host-callable launchers (declared in launch.h) ----
+size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
+  return (lds_scene ? size_t(p.sv.blob_f4) * 16 : 0) + size_t(p.stack_entries) * kBlock * 4 + 4 * kAccBytesPerWave;
+}
+
+hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, uint32_t n_blocks, hipStream_t stream) {
+  const size_t lds = pt_lds_bytes(p, lds_scene);
+  void (*fn)(const RenderParams) = nullptr;
+  if (lds_scene) fn = list ? pt_megakernel<true, true> : pt_megakernel<true, false>;
+  else fn = list ? pt_megakernel<false, true> : pt_megakernel<false, false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(kBlock), lds, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize(const double* partial, float* rgbn, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w,
+                           uint32_t h, uint32_t n_chunks, hipStream_t stream) {
+  const uint32_t n = width * height;
+  hipLaunchKernelGGL(pt_finalize, dim3((n + 255) / 256), dim3(256), 0, stream, partial, reinterpret_cast<float4*>(rgbn), width, height,
+                     x0, y0, w, h, n_chunks);
+  return hipGetLastError();
+}
+
+hipError_t launch_intersect(const SceneView& sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* origins, const float* dirs,
+                            mi_surface_point* out_hits, float* out_t, uint32_t* out_prim, hipStream_t stream) {
+  hipLaunchKernelGGL(k_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, n,
+                     origins, dirs, out_hits, out_t, out_prim);
+  return hipGetLastError();
+}
+
+hipError_t launch_occluded(const SceneView& sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* a, const mi_surface_point* b,
+                           float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_occluded, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, n, a, b,
+                     out);
+  return hipGetLastError();
+}
+
+}  // namespace mi

@@ -1,0 +1,68 @@
+// vecmath.h — float3 arithmetic of the device path (gfx950).
+//
+// The whole device side is compiled with -ffp-contract=off; fusion happens ONLY where this
+// header spells fmaf().  DESIGN.md "Arithmetic contract" lists these definitions; the CPU
+// oracle states the same ones independently, so results can be compared bit for bit:
+//   dot(a,b)      = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+//   cross(a,b).x  = fma(a.y,b.z, -(b.y*a.z))   (cyclic)
+//   M*v  (r)      = fma(M.c2[r],v.z, fma(M.c1[r],v.y, M.c0[r]*v.x))
+//   v*M  (i)      = dot(M.c[i], v)
+//   normalize(a)  = a * (1 / sqrt(dot(a,a)))
+//   madd(a,b,s)   = fma(b,s,a) per component
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+struct f3 { float x, y, z; };
+struct m33 { f3 c0, c1, c2; };  // column-major like glm::mat3
+
+#define MI_DEV __device__ __forceinline__
+
+MI_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+MI_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+MI_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+MI_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+MI_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+MI_DEV f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+MI_DEV f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+MI_DEV float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+MI_DEV f3 cross(f3 a, f3 b) {
+  return F3(fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y)));
+}
+MI_DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+MI_DEV f3 madd(f3 a, f3 b, float s) { return F3(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)); }
+MI_DEV float l1norm(f3 a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z); }
+MI_DEV float gsign(float x) { return float((0.0f < x) - (x < 0.0f)); }
+MI_DEV f3 mulmv(const m33& m, f3 v) {  // glm mat3 * vec3
+  return F3(fmaf(m.c2.x, v.z, fmaf(m.c1.x, v.y, m.c0.x * v.x)), fmaf(m.c2.y, v.z, fmaf(m.c1.y, v.y, m.c0.y * v.x)),
+            fmaf(m.c2.z, v.z, fmaf(m.c1.z, v.y, m.c0.z * v.x)));
+}
+MI_DEV f3 mulvm(f3 v, const m33& m) { return F3(dot(m.c0, v), dot(m.c1, v), dot(m.c2, v)); }  // glm vec3 * mat3
+
+#define MI_ONE_OVER_PI 0.318309886183790671537767526745028724f
+#define MI_PI 3.14159265358979323846264338327950288f
+#define MI_FLT_EPSILON 1.1920928955078125e-7f
+
+// sin / cos of phi = (u * 2) * pi for u in [0,1) (sample_lambert / sample_phong, Sample.inl:55,146).
+// Own definition (libm and the device math library differ in the last bits): quadrant
+// reduction on u, which is exact in binary floating point, then odd/even polynomials on
+// |theta| <= pi/4.  Max error ~1.5e-7 absolute.  The oracle states the same formula.
+MI_DEV void sincos_2pi(float u, float* s, float* c) {
+  float k = floorf(fmaf(u, 4.0f, 0.5f));  // nearest quadrant 0..4
+  float r = fmaf(k, -0.25f, u);           // exact: u - k/4 in [-1/8, 1/8]
+  float t = r * 6.28318530717958647692f;  // theta
+  float t2 = t * t;
+  // sin(t) ~ t + t^3 * P(t^2), cos(t) ~ 1 + t^2 * Q(t^2)   (Cephes sinf/cosf kernels)
+  float ps = fmaf(fmaf(-1.9515295891e-4f, t2, 8.3321608736e-3f), t2, -1.6666654611e-1f);
+  float sn = fmaf(t * t2, ps, t);
+  float pc = fmaf(fmaf(2.443315711809948e-5f, t2, -1.388731625493765e-3f), t2, 4.166664568298827e-2f);
+  float cs = fmaf(t2 * t2, pc, fmaf(t2, -0.5f, 1.0f));
+  int q = int(k) & 3;
+  float so = (q & 1) ? cs : sn, co = (q & 1) ? sn : cs;
+  *s = (q == 2 || q == 3) ? -so : so;
+  *c = (q == 1 || q == 2) ? -co : co;
+}
+
+}  // namespace mi

@@ -1,0 +1,395 @@
+// mi_pt_api.hip — host side of the C ABI (include/mi_pt.h): handle life cycle, scene upload,
+// LBVH build, render calls, parity hooks.  Everything that computes runs on the GPU; there is no
+// CPU fallback — without a HIP device every compute entry point fails with MI_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device/launch.h"
+#include "scene_host.hpp"
+
+using mi::fail;
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return fail(e_ == hipErrorOutOfMemory ? MI_ERR_OUT_OF_MEMORY : MI_ERR_NO_DEVICE,                  \
+                  std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " #expr " failed: " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct mi_pt_handle {
+  int device = 0;
+  mi::SceneData scene;
+  mi_pt_params params{};
+  float4* blob = nullptr;
+  mi::SceneView sv{};
+  uint32_t* d_sorted_tri = nullptr;
+  uint32_t* d_morton = nullptr;
+  mi_bvh_info info{};
+  int kernel_choice = MI_PT_KERNEL_AUTO;
+  bool lds_fits = false;
+  double* partial = nullptr; size_t partial_bytes = 0;
+  float* d_rgbn = nullptr; size_t rgbn_bytes = 0;
+  unsigned long long* d_counters = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+};
+
+namespace {
+
+constexpr size_t kLdsSceneLimit = 48 * 1024;  // blob bytes; keeps >= 2 workgroups per CU in the 160 KB LDS
+
+template <class T> int upload(T** dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), bytes ? bytes : 16));
+  if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return MI_OK;
+}
+
+float l1(const float* v) { return std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]); }
+
+int ensure(void** p, size_t* have, size_t need) {
+  if (*have >= need) return MI_OK;
+  if (*p) hipFree(*p);
+  *p = nullptr; *have = 0;
+  HIP_TRY(hipMalloc(p, need));
+  *have = need;
+  return MI_OK;
+}
+
+bool use_lds_scene(const mi_pt_handle* h) {
+  if (h->kernel_choice == MI_PT_KERNEL_MEGA_LDS) return h->lds_fits;
+  if (h->kernel_choice == MI_PT_KERNEL_MEGA_GLOBAL) return false;
+  return h->lds_fits;
+}
+
+int fill_camera(const mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi::RenderParams& p) {
+  if (camera_id >= h->scene.cameras.size()) return fail(MI_ERR_INVALID_ARGUMENT, "camera_id out of range");  // Cameras.cpp:48 runtime_assert
+  if (width == 0 || height == 0 || uint64_t(width) * height > (1ull << 31)) return fail(MI_ERR_INVALID_ARGUMENT, "bad resolution");
+  mi_camera_frame cf;
+  mi::camera_setup(h->scene.cameras[camera_id], float(width) / float(height), cf);  // Technique.cpp:37-45
+  std::memcpy(p.v2w, cf.view_to_world, sizeof p.v2w);
+  std::memcpy(p.cam_pos, cf.position, sizeof p.cam_pos);
+  p.focal_length_y = cf.focal_length_y;
+  p.res_x = float(width); p.res_y = float(height); p.res_y_inv = 1.0f / p.res_y;
+  p.width = width; p.height = height;
+  return MI_OK;
+}
+
+void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
+  p.sv = h->sv;
+  p.stack_entries = h->info.stack_entries;
+  const uint64_t mp = h->params.max_path;
+  p.max_path = mp > 0x7FFFFFFFull ? 0x7FFFFFFFu : uint32_t(mp);
+  p.min_subpath = h->params.min_subpath;
+  p.beta = h->params.beta; p.roulette = h->params.roulette; p.lights = h->params.lights;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int device, mi_pt_handle** out) {
+  if (!desc || !params || !out) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_create: null argument");
+  *out = nullptr;
+  mi_scene* tmp = nullptr;
+  int rc = mi_scene_from_desc(desc, &tmp);
+  if (rc != MI_OK) return rc;
+  if (!(params->roulette > 0.0f) || !(params->roulette <= 1.0f)) {  // Options.cpp: --roulette in (0,1]
+    mi_scene_free(tmp);
+    return fail(MI_ERR_INVALID_ARGUMENT, "roulette must be in (0, 1]");
+  }
+  if (tmp->data.lights.empty()) {  // AreaLights.cpp:217 runtime_assert(num_lights() != 0)
+    mi_scene_free(tmp);
+    return fail(MI_ERR_INVALID_ARGUMENT, "scene has no area lights");
+  }
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+    mi_scene_free(tmp);
+    return fail(MI_ERR_NO_DEVICE, "no HIP device available (libmi_pt has no CPU path)");
+  }
+  if (device < 0 || device >= n_dev) { mi_scene_free(tmp); return fail(MI_ERR_INVALID_ARGUMENT, "device index out of range"); }
+  mi_pt_handle* h = new mi_pt_handle();
+  h->device = device;
+  h->scene = std::move(tmp->data);
+  mi_scene_free(tmp);
+  h->params = *params;
+  if (h->params.min_subpath == 0) h->params.min_subpath = 3;  // PT.hpp:24
+  struct Guard { mi_pt_handle* h; ~Guard() { if (h) mi_pt_destroy(h); } } guard{h};
+
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreate(&h->stream));
+  HIP_TRY(hipEventCreate(&h->ev0)); HIP_TRY(hipEventCreate(&h->ev1)); HIP_TRY(hipEventCreate(&h->ev2));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_counters), 4 * sizeof(unsigned long long)));
+
+  const mi::SceneData& s = h->scene;
+  const uint32_t nt = uint32_t(s.indices.size() / 3), nmat = uint32_t(s.materials.size()), nl = uint32_t(s.lights.size());
+  const uint32_t n_nodes = nt > 1 ? nt - 1 : 0;
+
+  // blob layout (float4 units)
+  mi::SceneView sv{};
+  sv.n_tris = nt; sv.n_nodes = n_nodes; sv.n_mats = nmat; sv.n_lights = nl;
+  sv.off_nodes = 0;
+  sv.off_tris = sv.off_nodes + 4 * n_nodes;
+  sv.off_shade = sv.off_tris + 3 * nt;
+  sv.off_mats = sv.off_shade + 7 * nt;
+  sv.off_lights = sv.off_mats + 3 * nmat;
+  sv.off_cdf = sv.off_lights + 6 * nl;
+  sv.blob_f4 = sv.off_cdf + (nl + 1 + 3) / 4;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->blob), size_t(sv.blob_f4) * 16));
+  HIP_TRY(hipMemset(h->blob, 0, size_t(sv.blob_f4) * 16));
+  sv.blob = h->blob;
+  h->sv = sv;
+
+  // materials: mi_material with reserved := Phong diffuse probability (PhongBSDF ctor, BSDF.cpp:306-315)
+  {
+    std::vector<mi_material> mats = s.materials;
+    for (mi_material& m : mats) {
+      float pd = 0.0f;
+      if (m.type == MI_BSDF_PHONG) {
+        const float dr = l1(m.diffuse) * 0.318309886183790671537767526745028724f;
+        const float sr = l1(m.specular) * 2.0f * 3.14159265358979323846264338327950288f / (m.power + 1.0f);
+        pd = dr / (dr + sr);
+      }
+      std::memcpy(&m.reserved, &pd, 4);
+    }
+    static_assert(sizeof(mi_material) == 48, "mi_material must be 3 float4");
+    HIP_TRY(hipMemcpy(h->blob + sv.off_mats, mats.data(), mats.size() * sizeof(mi_material), hipMemcpyHostToDevice));
+  }
+  // lights + piecewise sampler (AreaLights::_updateSampler, AreaLights.cpp:199-214)
+  {
+    static_assert(sizeof(mi::DevLight) == 96, "DevLight must be 6 float4");
+    std::vector<mi::DevLight> dl(nl);
+    std::vector<float> cdf(size_t(nl + 1 + 3) / 4 * 4, 0.0f);
+    float total = 0.0f;
+    for (uint32_t i = 0; i < nl; ++i) total += (s.lights[i].size[0] * s.lights[i].size[1]) * l1(s.lights[i].exitance);
+    const float total_inv = 1.0f / total;
+    for (uint32_t i = 0; i < nl; ++i) {
+      const mi_light& l = s.lights[i];
+      mi::DevLight& d = dl[i];
+      std::memset(&d, 0, sizeof d);
+      const float area = l.size[0] * l.size[1];
+      const float weight = area * l1(l.exitance) * total_inv;
+      std::memcpy(d.position, l.position, 12); d.weight = weight;
+      std::memcpy(d.t0, l.tangent, 12); d.area = area;
+      std::memcpy(d.t1, l.tangent + 3, 12); d.size_x = l.size[0];
+      std::memcpy(d.t2, l.tangent + 6, 12); d.size_y = l.size[1];
+      for (int k = 0; k < 3; ++k) d.radiance[k] = l.exitance[k] * 0.318309886183790671537767526745028724f;  // AreaLights.hpp:54
+      d.material_id = l.material_id;
+      d.lsdf_density = weight / area;
+      d.area_density = 1.0f / area;
+      d.diffuse = l.diffuse;
+      cdf[i + 1] = cdf[i] + weight;
+    }
+    HIP_TRY(hipMemcpy(h->blob + sv.off_lights, dl.data(), dl.size() * sizeof(mi::DevLight), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->blob + sv.off_cdf, cdf.data(), cdf.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // geometry upload + on-device LBVH
+  {
+    std::vector<uint32_t> tri_material(nt);
+    for (size_t m = 0; m + 1 < s.mesh_tri_offset.size(); ++m)
+      for (uint32_t t = s.mesh_tri_offset[m]; t < s.mesh_tri_offset[m + 1]; ++t) tri_material[t] = s.mesh_material_id[m];
+    float *d_pos = nullptr, *d_tan = nullptr; uint32_t *d_idx = nullptr, *d_tm = nullptr;
+    struct Tmp { void* p[4]; ~Tmp() { for (void* q : p) if (q) hipFree(q); } } tmpbuf{{nullptr, nullptr, nullptr, nullptr}};
+    rc = upload(&d_pos, s.positions.data(), s.positions.size() * 4); tmpbuf.p[0] = d_pos; if (rc) return rc;
+    rc = upload(&d_tan, s.tangents.data(), s.tangents.size() * 4); tmpbuf.p[1] = d_tan; if (rc) return rc;
+    rc = upload(&d_idx, s.indices.data(), s.indices.size() * 4); tmpbuf.p[2] = d_idx; if (rc) return rc;
+    rc = upload(&d_tm, tri_material.data(), tri_material.size() * 4); tmpbuf.p[3] = d_tm; if (rc) return rc;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_sorted_tri), size_t(nt) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_morton), size_t(nt) * 4));
+    float build_ms = 0.0f; uint32_t depth = 1;
+    HIP_TRY(mi::build_lbvh(nt, d_pos, d_tan, d_idx, d_tm, reinterpret_cast<mi_bvh_node*>(h->blob + sv.off_nodes), h->blob + sv.off_tris,
+                           h->blob + sv.off_shade, h->d_sorted_tri, h->d_morton, h->info.scene_lo, h->info.scene_hi, &depth, &build_ms,
+                           h->stream));
+    h->info.n_triangles = nt; h->info.n_nodes = n_nodes; h->info.max_depth = depth; h->info.build_ms = build_ms;
+    uint32_t se = (depth + 7u) / 8u * 8u;  // pending far children <= depth - 1
+    if (se < 8) se = 8;
+    if (se > 128) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the 128-entry traversal stack");
+    h->info.stack_entries = se;
+  }
+  h->lds_fits = size_t(sv.blob_f4) * 16 <= kLdsSceneLimit;
+  guard.h = nullptr;
+  *out = h;
+  return MI_OK;
+}
+
+void mi_pt_destroy(mi_pt_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->blob) hipFree(h->blob);
+  if (h->d_sorted_tri) hipFree(h->d_sorted_tri);
+  if (h->d_morton) hipFree(h->d_morton);
+  if (h->partial) hipFree(h->partial);
+  if (h->d_rgbn) hipFree(h->d_rgbn);
+  if (h->d_counters) hipFree(h->d_counters);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->ev2) hipEventDestroy(h->ev2);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int mi_pt_set_kernel(mi_pt_handle* h, int kernel) {
+  if (!h || kernel < MI_PT_KERNEL_AUTO || kernel > MI_PT_KERNEL_MEGA_GLOBAL) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_set_kernel: bad argument");
+  if (kernel == MI_PT_KERNEL_MEGA_LDS && !h->lds_fits) return fail(MI_ERR_UNSUPPORTED, "scene does not fit the LDS-resident kernel");
+  h->kernel_choice = kernel;
+  return MI_OK;
+}
+int mi_pt_get_kernel(mi_pt_handle* h) {
+  if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "null handle");
+  return use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
+}
+
+int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp,
+                        uint64_t seed, uint64_t sample_offset, float* rgbn_sum_device, void* stream_v, mi_pt_stats* stats) {
+  if (!h || !rgbn_sum_device) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render: null argument");
+  if (spp == 0) return fail(MI_ERR_INVALID_ARGUMENT, "spp must be > 0");
+  mi::RenderParams p;
+  std::memset(&p, 0, sizeof p);
+  int rc = fill_camera(h, camera_id, width, height, p);
+  if (rc) return rc;
+  if (win.w == 0 || win.h == 0) { win.x0 = 0; win.y0 = 0; win.w = width; win.h = height; }
+  if (uint64_t(win.x0) + win.w > width || uint64_t(win.y0) + win.h > height)
+    return fail(MI_ERR_INVALID_ARGUMENT, "window exceeds the image");  // Technique.cpp:318-319 runtime_assert
+  fill_pt(h, p);
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->stream;
+
+  p.win_x0 = win.x0; p.win_y0 = win.y0; p.win_w = win.w; p.win_h = win.h;
+  p.tiles_x = (win.w + 7) / 8; p.tiles_y = (win.h + 7) / 8;
+  const uint64_t n_tiles = uint64_t(p.tiles_x) * p.tiles_y;
+  // sample chunks: enough waves to fill and balance the chip (256 CUs x ~16 waves, x8 rounds)
+  // while a wave still amortises its start-up over >= 32 samples per pixel.
+  uint64_t n_chunks = (32768 + n_tiles - 1) / n_tiles;
+  const uint64_t max_chunks = spp >= 64 ? spp / 32 : 1;
+  if (n_chunks > max_chunks) n_chunks = max_chunks;
+  if (n_chunks < 1) n_chunks = 1;
+  p.chunk_spp = uint32_t((spp + n_chunks - 1) / n_chunks);
+  p.n_chunks = (spp + p.chunk_spp - 1) / p.chunk_spp;
+  p.spp = spp; p.seed = seed; p.sample_offset = sample_offset;
+  const uint64_t n_waves = n_tiles * p.n_chunks;
+  const uint64_t n_blocks = (n_waves + 3) / 4;
+  if (n_blocks > 0x7FFFFFFFull) return fail(MI_ERR_UNSUPPORTED, "render too large for one launch");
+
+  rc = ensure(reinterpret_cast<void**>(&h->partial), &h->partial_bytes, size_t(p.n_chunks) * width * height * 32);
+  if (rc) return rc;
+  p.partial = h->partial;
+  p.counters = h->d_counters;
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipEventRecord(h->ev0, stream));
+  HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), false, uint32_t(n_blocks), stream));
+  HIP_TRY(hipEventRecord(h->ev1, stream));
+  HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
+  HIP_TRY(hipEventRecord(h->ev2, stream));
+  if (stats) {
+    unsigned long long c[4];
+    HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float t01 = 0.0f, t02 = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&t01, h->ev0, h->ev1));
+    HIP_TRY(hipEventElapsedTime(&t02, h->ev0, h->ev2));
+    stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
+    stats->trace_ms = t01; stats->gpu_ms = t02;
+  }
+  return MI_OK;
+}
+
+int mi_pt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint64_t seed,
+                 uint64_t sample_offset, float* rgbn_sum, mi_pt_stats* stats) {
+  if (!h || !rgbn_sum) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render: null argument");
+  if (width == 0 || height == 0 || uint64_t(width) * height > (1ull << 31)) return fail(MI_ERR_INVALID_ARGUMENT, "bad resolution");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t bytes = size_t(width) * height * 16;
+  int rc = ensure(reinterpret_cast<void**>(&h->d_rgbn), &h->rgbn_bytes, bytes);
+  if (rc) return rc;
+  mi_pt_stats local;
+  rc = mi_pt_render_device(h, camera_id, width, height, win, spp, seed, sample_offset, h->d_rgbn, nullptr, stats ? stats : &local);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(rgbn_sum, h->d_rgbn, bytes, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_pt_intersect(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins, const float* directions, mi_surface_point* out_hits,
+                    float* out_t, uint32_t* out_prim) {
+  if (!h || (n && (!origins || !directions))) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_intersect: null argument");
+  if (n == 0) return MI_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  mi_surface_point *d_o = nullptr, *d_h = nullptr; float *d_d = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;
+  struct Tmp { void* p[5]; ~Tmp() { for (void* q : p) if (q) hipFree(q); } } tmp{{nullptr, nullptr, nullptr, nullptr, nullptr}};
+  int rc = upload(&d_o, origins, size_t(n) * sizeof(mi_surface_point)); tmp.p[0] = d_o; if (rc) return rc;
+  rc = upload(&d_d, directions, size_t(n) * 12); tmp.p[1] = d_d; if (rc) return rc;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_h), size_t(n) * sizeof(mi_surface_point))); tmp.p[2] = d_h;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_t), size_t(n) * 4)); tmp.p[3] = d_t;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_p), size_t(n) * 4)); tmp.p[4] = d_p;
+  HIP_TRY(mi::launch_intersect(h->sv, h->info.stack_entries, n, d_o, d_d, d_h, d_t, d_p, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (out_hits) HIP_TRY(hipMemcpy(out_hits, d_h, size_t(n) * sizeof(mi_surface_point), hipMemcpyDeviceToHost));
+  if (out_t) HIP_TRY(hipMemcpy(out_t, d_t, size_t(n) * 4, hipMemcpyDeviceToHost));
+  if (out_prim) HIP_TRY(hipMemcpy(out_prim, d_p, size_t(n) * 4, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_pt_occluded(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins, const mi_surface_point* targets, float* out_visibility) {
+  if (!h || (n && (!origins || !targets || !out_visibility))) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_occluded: null argument");
+  if (n == 0) return MI_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  mi_surface_point *d_a = nullptr, *d_b = nullptr; float* d_o = nullptr;
+  struct Tmp { void* p[3]; ~Tmp() { for (void* q : p) if (q) hipFree(q); } } tmp{{nullptr, nullptr, nullptr}};
+  int rc = upload(&d_a, origins, size_t(n) * sizeof(mi_surface_point)); tmp.p[0] = d_a; if (rc) return rc;
+  rc = upload(&d_b, targets, size_t(n) * sizeof(mi_surface_point)); tmp.p[1] = d_b; if (rc) return rc;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_o), size_t(n) * 4)); tmp.p[2] = d_o;
+  HIP_TRY(mi::launch_occluded(h->sv, h->info.stack_entries, n, d_a, d_b, d_o, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out_visibility, d_o, size_t(n) * 4, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_pt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_xy,
+                      const uint64_t* sample_index, uint64_t seed, float* out_radiance, uint32_t* out_ray_counts) {
+  if (!h || (n && (!pixel_xy || !sample_index || !out_radiance))) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_trace_paths: null argument");
+  if (n == 0) return MI_OK;
+  mi::RenderParams p;
+  std::memset(&p, 0, sizeof p);
+  int rc = fill_camera(h, camera_id, width, height, p);
+  if (rc) return rc;
+  for (uint32_t i = 0; i < n; ++i)
+    if (pixel_xy[2 * i] >= width || pixel_xy[2 * i + 1] >= height) return fail(MI_ERR_INVALID_ARGUMENT, "pixel outside the image");
+  fill_pt(h, p);
+  HIP_TRY(hipSetDevice(h->device));
+  uint32_t *d_xy = nullptr, *d_c = nullptr; uint64_t* d_s = nullptr; float* d_r = nullptr;
+  struct Tmp { void* p[4]; ~Tmp() { for (void* q : p) if (q) hipFree(q); } } tmp{{nullptr, nullptr, nullptr, nullptr}};
+  rc = upload(&d_xy, pixel_xy, size_t(n) * 8); tmp.p[0] = d_xy; if (rc) return rc;
+  rc = upload(&d_s, sample_index, size_t(n) * 8); tmp.p[1] = d_s; if (rc) return rc;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_r), size_t(n) * 12)); tmp.p[2] = d_r;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_c), size_t(n) * 8)); tmp.p[3] = d_c;
+  p.win_w = width; p.win_h = height;
+  p.seed = seed; p.list_xy = d_xy; p.list_sample = d_s; p.list_n = n; p.list_radiance = d_r; p.list_counts = d_c;
+  p.counters = nullptr;
+  const uint32_t per_block = 4u * 64u * 16u;
+  HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), true, (n + per_block - 1) / per_block, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out_radiance, d_r, size_t(n) * 12, hipMemcpyDeviceToHost));
+  if (out_ray_counts) HIP_TRY(hipMemcpy(out_ray_counts, d_c, size_t(n) * 8, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_pt_bvh_info(mi_pt_handle* h, mi_bvh_info* out) {
+  if (!h || !out) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_bvh_info: null argument");
+  *out = h->info;
+  return MI_OK;
+}
+
+int mi_pt_bvh_download(mi_pt_handle* h, mi_bvh_node* nodes, uint32_t* sorted_tri, uint32_t* morton) {
+  if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_bvh_download: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  static_assert(sizeof(mi_bvh_node) == 64, "mi_bvh_node must be 4 float4");
+  if (nodes && h->sv.n_nodes) HIP_TRY(hipMemcpy(nodes, h->blob + h->sv.off_nodes, size_t(h->sv.n_nodes) * 64, hipMemcpyDeviceToHost));
+  if (sorted_tri) HIP_TRY(hipMemcpy(sorted_tri, h->d_sorted_tri, size_t(h->sv.n_tris) * 4, hipMemcpyDeviceToHost));
+  if (morton) HIP_TRY(hipMemcpy(morton, h->d_morton, size_t(h->sv.n_tris) * 4, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+}  // extern "C"

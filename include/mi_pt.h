@@ -132,6 +132,11 @@ typedef struct mi_pt_stats {
   uint64_t numeric_errors;   /* samples dropped as non-finite (Technique.cpp:224-230)           */
   double gpu_ms;             /* device time of the render kernels of this call (HIP events)     */
   double trace_ms;           /* device time of the dominant (path tracing) kernel alone         */
+  /* traversal work counters, filled only after mi_pt_set_instrumented(h, 1) (zero otherwise);
+   * they feed the roofline's algorithmic bytes (64 B per node, 48 B per triangle) */
+  uint64_t nodes_closest, tris_closest;  /* BVH nodes fetched / triangles tested by closest-hit rays */
+  uint64_t nodes_shadow, tris_shadow;    /* the same for shadow rays                                 */
+  uint64_t num_hits;                     /* closest-hit rays that hit a surface                      */
 } mi_pt_stats;
 
 typedef struct mi_pt_handle mi_pt_handle;
@@ -178,6 +183,8 @@ int mi_pt_abi_version(void);
 enum { MI_PT_KERNEL_AUTO = 0, MI_PT_KERNEL_MEGA_LDS = 1, MI_PT_KERNEL_MEGA_GLOBAL = 2 };
 int mi_pt_set_kernel(mi_pt_handle* h, int kernel);
 int mi_pt_get_kernel(mi_pt_handle* h); /* variant AUTO resolves to for this scene */
+/* 1: render calls run the instrumented kernel variant (same results, plus visit counters). */
+int mi_pt_set_instrumented(mi_pt_handle* h, int on);
 
 /* ------------------------------------------------------------------------------------------
  * Scene services exposed for parity tests (each is a batched form of one Scene method)

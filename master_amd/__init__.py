@@ -72,7 +72,9 @@ class Window(C.Structure):
 
 class PtStats(C.Structure):
     _fields_ = [("num_paths", C.c_uint64), ("num_basic_rays", C.c_uint64), ("num_shadow_rays", C.c_uint64), ("numeric_errors", C.c_uint64),
-                ("gpu_ms", C.c_double), ("trace_ms", C.c_double)]
+                ("gpu_ms", C.c_double), ("trace_ms", C.c_double),
+                ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
+                ("num_hits", C.c_uint64)]
 
 
 class SurfacePoint(C.Structure):
@@ -106,7 +108,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 # every symbol include/mi_pt.h declares; tests/test_abi.py checks the library exports them all
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version",
-    "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
+    "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
     "mi_pt_bvh_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
     "mi_scene_load", "mi_scene_save", "mi_scene_from_desc", "mi_scene_get_desc", "mi_scene_material_name", "mi_scene_mesh_name",
     "mi_scene_free", "mi_exr_save_rgbn", "mi_exr_load_rgbn", "mi_free", "mi_rms_abs_errors",
@@ -132,6 +134,7 @@ def lib():
     L.mi_pt_render_device.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, vp, C.POINTER(PtStats)]
     L.mi_pt_set_kernel.argtypes = [vp, C.c_int]
     L.mi_pt_get_kernel.argtypes = [vp]
+    L.mi_pt_set_instrumented.argtypes = [vp, C.c_int]
     L.mi_pt_intersect.argtypes = [vp, u32, vp, vp, vp, vp, vp]
     L.mi_pt_occluded.argtypes = [vp, u32, vp, vp, vp]
     L.mi_pt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp]
@@ -386,6 +389,9 @@ class PathTracing:
 
     def get_kernel(self):
         return lib().mi_pt_get_kernel(self._h)
+
+    def set_instrumented(self, on):
+        _check(lib().mi_pt_set_instrumented(self._h, 1 if on else 0))
 
     def intersect(self, origins, directions):
         """Scene::intersect + querySurface for n rays.  origins: SURFACE_DTYPE array."""

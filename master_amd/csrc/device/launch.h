@@ -13,7 +13,7 @@ hipError_t build_lbvh(uint32_t nt, const float* pos, const float* tan, const uin
                       float scene_lo[3], float scene_hi[3], uint32_t* max_depth_out, float* build_ms, hipStream_t stream);
 
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene);
-hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, uint32_t n_blocks, hipStream_t stream);
+hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_finalize(const double* partial, float* rgbn, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w,
                            uint32_t h, uint32_t n_chunks, hipStream_t stream);
 hipError_t launch_intersect(const SceneView& sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* origins, const float* dirs,

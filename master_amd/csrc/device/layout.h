@@ -52,7 +52,7 @@ struct RenderParams {
   float beta, roulette, lights;
   // outputs
   double* partial;        // [n_chunks][height*width][4] (r, g, b sums, count)
-  unsigned long long* counters;  // [4]: basic rays, shadow rays, numeric errors, paths
+  unsigned long long* counters;  // [9]: basic rays, shadow rays, numeric errors, paths, + instrumented: nodes/tris visited by closest-hit rays, by shadow rays, closest-hit rays that hit
   // list mode (mi_pt_trace_paths)
   const uint32_t* list_xy; const uint64_t* list_sample; uint32_t list_n;
   float* list_radiance; uint32_t* list_counts;

@@ -70,12 +70,17 @@ MI_DEV bool box_test(f3 lo, f3 hi, f3 org, f3 inv, float tmax, float& tnear) {
 
 // BVH2 traversal with a per-lane stack in LDS (stack[level * kBlock + tid]: consecutive lanes
 // hit consecutive banks).  `sb` = scene blob base (LDS or HBM).
-template <bool ANY>
+// Visit counters (nodes fetched, triangles tested) feed the roofline's algorithmic-bytes figure; they
+// are only live in the instrumented kernel variant (COUNT) and compile away otherwise.
+struct Visits { uint32_t nodes, tris; };
+
+template <bool ANY, bool COUNT = false>
 MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_t* __restrict__ stack, f3 org, f3 dir,
-                     uint32_t ray_mask, Hit& h) {
+                     uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
   const float4* nodes = sb + sv.off_nodes;
   const float4* tris = sb + sv.off_tris;
   if (sv.n_nodes == 0) {
+    if (COUNT) ++vis->tris;
     tri_test<ANY>(tris, 0, org, dir, ray_mask, h);
     return;
   }
@@ -85,6 +90,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_
   for (;;) {
     if (node >= 0) {
       const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+      if (COUNT) ++vis->nodes;
       float tn0, tn1;
       const bool h0 = box_test(xyz(n0), xyz(n1), org, inv, h.t, tn0);
       const bool h1 = box_test(xyz(n2), xyz(n3), org, inv, h.t, tn1);
@@ -101,6 +107,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_
         continue;
       }
     } else {
+      if (COUNT) ++vis->tris;
       const bool hit = tri_test<ANY>(tris, uint32_t(~node), org, dir, ray_mask, h);
       if (ANY && hit) return;
     }
@@ -147,13 +154,14 @@ MI_DEV f3 nudge(f3 position, f3 gnormal, f3 dir) {
 }
 
 // Scene::occluded (Scene.cpp:151-180): 1 = visible.
+template <bool COUNT = false>
 MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, uint32_t* stack, f3 opos, f3 ognormal, f3 tpos,
-                      f3 tgnormal) {
+                      f3 tgnormal, Visits* vis = nullptr) {
   const f3 direction = normalize(tpos - opos);
   const f3 ao = opos + (ognormal * (dot(ognormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   const f3 at = tpos + (tgnormal * (dot(tgnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   Hit h; h.t = 1.0f; h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-  traverse<true>(sb, sv, stack, ao, at - ao, 1u << MI_ENTITY_MESH, h);
+  traverse<true, COUNT>(sb, sv, stack, ao, at - ao, 1u << MI_ENTITY_MESH, h, vis);
   return h.id != 0xFFFFFFFFu ? 0.f : 1.f;
 }
 
@@ -298,8 +306,9 @@ MI_DEV float powb(float x, float beta) { return beta == 1.0f ? x : (beta == 2.0f
 // PathTracing::_connect (PT.cpp:100-120) incl. AreaLights::sample (AreaLights.cpp:121-140,216-231),
 // LightBSDF::query / sun_light_bsdf::query (BSDF.cpp:95-114,181-191; only .throughput is used),
 // Edge (SurfacePoint.hpp:65-83) and the shadow ray.
+template <bool COUNT = false>
 MI_DEV f3 connect(const float4* __restrict__ sb, const SceneView& sv, uint32_t* stack, Rng& g, const Material& mat,
-                  const Surf& x, f3 x_omega, f3 x_throughput, float beta, uint32_t& n_shadow) {
+                  const Surf& x, f3 x_omega, f3 x_throughput, float beta, uint32_t& n_shadow, Visits* vis = nullptr) {
   const float u = rng_f(g);
   const float* cdf = reinterpret_cast<const float*>(sb + sv.off_cdf);
   uint32_t id = sv.n_lights - 1;
@@ -326,7 +335,7 @@ MI_DEV f3 connect(const float4* __restrict__ sb, const SceneView& sv, uint32_t* 
   const float bG = distSqInv * bCos;
   const float cd = l5.y * l0.w;  // area_density * light_density
   const float wInv = powb(eb.densityRev * bG, beta) / powb(cd, beta) + 1.0f;
-  const float occ = occluded(sb, sv, stack, x.position, x.gnormal, lpos, lnormal);
+  const float occ = occluded<COUNT>(sb, sv, stack, x.position, x.gnormal, lpos, lnormal, vis);
   ++n_shadow;
   f3 r = (xyz(l4) * occ) / cd;
   r = r * x_throughput;

@@ -31,7 +31,7 @@ MI_DEV uint32_t wave_sum(uint32_t v) {
 
 constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4;
 
-template <bool LDS_SCENE, bool LIST>
+template <bool LDS_SCENE, bool LIST, bool COUNT>
 __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
   extern __shared__ float4 smem[];
   const uint32_t tid = threadIdx.x;
@@ -101,6 +101,8 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
   uint32_t pix = 0, item_id = 0;
   uint32_t n_basic = 0, n_shadow = 0, n_err = 0, n_paths = 0;
   uint32_t path_basic = 0, path_shadow = 0;  // LIST mode per-path counts
+  Visits vis_c = {0u, 0u}, vis_s = {0u, 0u};  // instrumented variant only
+  uint32_t n_hits = 0;
 
   for (;;) {
     // ---- path regeneration: dead lanes take the next samples of the wave's pool ----
@@ -145,8 +147,9 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
     if (alive) {
       // ---- Scene::intersect (Scene.cpp:182-203) ----
       Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-      traverse<false>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h);
+      traverse<false, COUNT>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
       ++n_basic; ++path_basic;
+      if (COUNT && h.id != 0xFFFFFFFFu) ++n_hits;
 
       bool terminate = false, do_vertex = false;
       Surf sp;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
         const Material mat = load_material(sb, sv, sp.material_id);
         const f3 x_omega = -dir;
         uint32_t ns = 0;
-        radiance = radiance + connect(sb, sv, stack, rng, mat, sp, x_omega, x_throughput, p.beta, ns);
+        radiance = radiance + connect<COUNT>(sb, sv, stack, rng, mat, sp, x_omega, x_throughput, p.beta, ns, &vis_s);
         n_shadow += ns; path_shadow += ns;
         const BSample bs = bsdf_sample(mat, rng, sp, x_omega);
         const float bCos = fabsf(dot(-bs.omega, sp.tangent.c1));  // Edge::bCosTheta with omega = -bsdf.omega
@@ -253,6 +256,14 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
     if (ss_) atomicAdd(&p.counters[1], (unsigned long long)ss_);
     if (se_) atomicAdd(&p.counters[2], (unsigned long long)se_);
     if (sp_) atomicAdd(&p.counters[3], (unsigned long long)sp_);
+  }
+  if (COUNT && p.counters) {
+    const uint32_t v0 = wave_sum(vis_c.nodes), v1 = wave_sum(vis_c.tris), v2 = wave_sum(vis_s.nodes), v3 = wave_sum(vis_s.tris), v4 = wave_sum(n_hits);
+    if (lane == 0) {
+      atomicAdd(&p.counters[4], (unsigned long long)v0); atomicAdd(&p.counters[5], (unsigned long long)v1);
+      atomicAdd(&p.counters[6], (unsigned long long)v2); atomicAdd(&p.counters[7], (unsigned long long)v3);
+      atomicAdd(&p.counters[8], (unsigned long long)v4);
+    }
   }
 }
 
@@ -329,11 +340,12 @@ size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
   return (lds_scene ? size_t(p.sv.blob_f4) * 16 : 0) + size_t(p.stack_entries) * kBlock * 4 + 4 * kAccBytesPerWave;
 }
 
-hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, uint32_t n_blocks, hipStream_t stream) {
+hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream) {
   const size_t lds = pt_lds_bytes(p, lds_scene);
   void (*fn)(const RenderParams) = nullptr;
-  if (lds_scene) fn = list ? pt_megakernel<true, true> : pt_megakernel<true, false>;
-  else fn = list ? pt_megakernel<false, true> : pt_megakernel<false, false>;
+  if (count) fn = lds_scene ? pt_megakernel<true, false, true> : pt_megakernel<false, false, true>;
+  else if (lds_scene) fn = list ? pt_megakernel<true, true, false> : pt_megakernel<true, false, false>;
+  else fn = list ? pt_megakernel<false, true, false> : pt_megakernel<false, false, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(kBlock), lds, stream, p);

@@ -31,6 +31,7 @@ struct mi_pt_handle {
   uint32_t* d_morton = nullptr;
   mi_bvh_info info{};
   int kernel_choice = MI_PT_KERNEL_AUTO;
+  bool instrumented = false;
   bool lds_fits = false;
   double* partial = nullptr; size_t partial_bytes = 0;
   float* d_rgbn = nullptr; size_t rgbn_bytes = 0;
@@ -123,7 +124,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreate(&h->stream));
   HIP_TRY(hipEventCreate(&h->ev0)); HIP_TRY(hipEventCreate(&h->ev1)); HIP_TRY(hipEventCreate(&h->ev2));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_counters), 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_counters), 16 * sizeof(unsigned long long)));
 
   const mi::SceneData& s = h->scene;
   const uint32_t nt = uint32_t(s.indices.size() / 3), nmat = uint32_t(s.materials.size()), nl = uint32_t(s.lights.size());
@@ -238,6 +239,11 @@ int mi_pt_set_kernel(mi_pt_handle* h, int kernel) {
   h->kernel_choice = kernel;
   return MI_OK;
 }
+int mi_pt_set_instrumented(mi_pt_handle* h, int on) {
+  if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "null handle");
+  h->instrumented = on != 0;
+  return MI_OK;
+}
 int mi_pt_get_kernel(mi_pt_handle* h) {
   if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "null handle");
   return use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
@@ -278,14 +284,14 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
   if (rc) return rc;
   p.partial = h->partial;
   p.counters = h->d_counters;
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 16 * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(h->ev0, stream));
-  HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), false, uint32_t(n_blocks), stream));
+  HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), false, h->instrumented, uint32_t(n_blocks), stream));
   HIP_TRY(hipEventRecord(h->ev1, stream));
   HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
   HIP_TRY(hipEventRecord(h->ev2, stream));
   if (stats) {
-    unsigned long long c[4];
+    unsigned long long c[9];
     HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     float t01 = 0.0f, t02 = 0.0f;
@@ -293,6 +299,7 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
     HIP_TRY(hipEventElapsedTime(&t02, h->ev0, h->ev2));
     stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
     stats->trace_ms = t01; stats->gpu_ms = t02;
+    stats->nodes_closest = c[4]; stats->tris_closest = c[5]; stats->nodes_shadow = c[6]; stats->tris_shadow = c[7]; stats->num_hits = c[8];
   }
   return MI_OK;
 }
@@ -369,7 +376,7 @@ int mi_pt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint3
   p.seed = seed; p.list_xy = d_xy; p.list_sample = d_s; p.list_n = n; p.list_radiance = d_r; p.list_counts = d_c;
   p.counters = nullptr;
   const uint32_t per_block = 4u * 64u * 16u;
-  HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), true, (n + per_block - 1) / per_block, h->stream));
+  HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), true, false, (n + per_block - 1) / per_block, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_radiance, d_r, size_t(n) * 12, hipMemcpyDeviceToHost));
   if (out_ray_counts) HIP_TRY(hipMemcpy(out_ray_counts, d_c, size_t(n) * 8, hipMemcpyDeviceToHost));

@@ -1,0 +1,229 @@
+"""Parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for integer / index work (LBVH, primitive ids, ray counts, sample counts) and —
+because oracle and device state the same arithmetic contract — bit-exact for the FP32 results of
+the diffuse / mirror / dielectric paths too.  Where a library pow() is involved (Phong, beta not
+in {1, 2}) the tolerance is written in the test.  Full-size runs use size-independent properties
+(sample counts, additivity over sample ranges, determinism, furnace value)."""
+import numpy as np
+import pytest
+
+import master_amd as ma
+import oracle
+import scene_builders as sb
+from conftest import load_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def rays(scene, n, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = scene.positions.min(0), scene.positions.max(0)
+    o = np.zeros(n, ma.SURFACE_DTYPE)
+    o["position"] = rng.uniform(lo, hi, (n, 3)); g = rng.normal(size=(n, 3)); o["gnormal"] = g / np.linalg.norm(g, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+def grid_paths(w, h, spp):
+    xy = np.stack(np.meshgrid(np.arange(w), np.arange(h)), -1).reshape(-1, 2).astype(np.uint32)
+    return np.tile(xy, (spp, 1)), np.repeat(np.arange(spp, dtype=np.uint64), w * h)
+
+
+SCENES = ["CornellBoxDiffuse", "CornellBoxSpecular", "TestCaseFurnace", "TestCase0", "DoubleLight", "soup300", "soup20000", "single"]
+
+
+def get_scene(name):
+    if name.startswith("soup"):
+        return sb.random_soup(int(name[4:]), seed=11)
+    if name == "single":  # one surface triangle + light: n_nodes = 1, exercises the tiny-tree paths
+        b = sb.Builder()
+        b.add_camera((0, -3, 0.5), (0, 1, 0))
+        m = b.add_material(sb.material(ma.BSDF_DIFFUSE, diffuse=(0.5, 0.5, 0.5)))
+        b.add_mesh([[(-1, 0, 0), (1, 0, 0), (0, 0, 1.5)]], m)
+        b.add_light((0, -1, 2), (0, 0.5, -1), (0, 1, 0.5), (0.5, 0.5), (5, 5, 5))
+        return b.build()
+    return load_scene(name)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_lbvh_bit_exact(name):
+    s = get_scene(name)
+    pt, orc = ma.PathTracing(s), oracle.Oracle(s)
+    gi, oi = pt.bvh_info(), orc.bvh_info()
+    assert (gi.n_nodes, gi.max_depth) == (oi.n_nodes, oi.max_depth)
+    assert list(gi.scene_lo) == list(oi.scene_lo) and list(gi.scene_hi) == list(oi.scene_hi)
+    gn, gs, gm = pt.bvh(); on, os_, om = orc.bvh()
+    assert np.array_equal(gm, om) and np.array_equal(gs, os_)
+    assert gn.tobytes() == on.tobytes()
+    assert gi.stack_entries >= gi.max_depth - 1
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_intersect_and_occluded_bit_exact(name):
+    s = get_scene(name)
+    pt, orc = ma.PathTracing(s), oracle.Oracle(s)
+    o, d = rays(s, 100000, 1)
+    gh, gt, gp = pt.intersect(o, d); oh, ot, op = orc.intersect(o, d)
+    assert np.array_equal(gp, op) and np.array_equal(gt, ot) and gh.tobytes() == oh.tobytes()
+    tg, _ = rays(s, 100000, 2)
+    assert np.array_equal(pt.occluded(o, tg), orc.occluded(o, tg))
+    # traversal == brute force (oracle without its BVH): exact t, exact primitive
+    orc.set_use_bvh(False)
+    _, bt, bp = orc.intersect(o[:20000], d[:20000])
+    assert np.array_equal(gp[:20000], bp) and np.array_equal(gt[:20000], bt)
+
+
+def test_intersect_edge_cases(cornell):
+    pt, orc = ma.PathTracing(cornell), oracle.Oracle(cornell)
+    o, d = rays(cornell, 64, 3)
+    d[:16] = [0, 0, 1]; d[16:32] = [1, 0, 0]; d[32:40] = [0, -1, 0]       # axis-parallel: 1/0 slabs
+    o["position"][40:48] = cornell.positions[cornell.indices[:8, 0]]          # start exactly on vertices
+    o["position"][48:56] = [1e6, 1e6, 1e6]                                    # far outside
+    gh, gt, gp = pt.intersect(o, d); oh, ot, op = orc.intersect(o, d)
+    assert np.array_equal(gp, op) and np.array_equal(gt, ot) and gh.tobytes() == oh.tobytes()
+    h, t, p = pt.intersect(o[:0], d[:0])                                       # empty batch
+    assert len(h) == 0
+
+
+@pytest.mark.parametrize("name,max_path", [("CornellBoxDiffuse", 8), ("CornellBoxDiffuse", 1), ("CornellBoxDiffuse", 2), ("CornellBoxDiffuse", 0),
+                                           ("TestCaseFurnace", ma.PTRDIFF_MAX), ("CornellBoxSpecular", 12), ("DoubleLight", 6), ("single", 4)])
+def test_per_path_radiance_bit_exact(name, max_path):
+    s = get_scene(name)
+    pt, orc = ma.PathTracing(s, max_path=max_path), oracle.Oracle(s, max_path=max_path)
+    xy, si = grid_paths(48, 40, 6)
+    gr, gc = pt.trace_paths(48, 40, xy, si, seed=7); orr, oc = orc.trace_paths(48, 40, xy, si, seed=7)
+    assert np.array_equal(gc, oc)
+    if name in ("DoubleLight",):  # Phong materials: library powf differs in the last bits between libm and the device
+        np.testing.assert_allclose(gr, orr, rtol=2e-5, atol=1e-7)
+    else:
+        same = (gr.view(np.uint32) == orr.view(np.uint32)) | (np.isnan(gr) & np.isnan(orr))
+        assert same.all(), "mismatching paths: %s" % np.nonzero(~same.all(1))[0][:10]
+
+
+@pytest.mark.parametrize("beta,roulette,lights", [(2.0, 0.5, 1.0), (1.0, 1.0, 0.0), (1.5, 0.9, 1.0), (0.0, 0.3, 2.0)])
+def test_parameters_follow_the_reference_semantics(cornell, beta, roulette, lights):
+    pt = ma.PathTracing(cornell, max_path=6, beta=beta, roulette=roulette, lights=lights)
+    orc = oracle.Oracle(cornell, max_path=6, beta=beta, roulette=roulette, lights=lights)
+    xy, si = grid_paths(32, 32, 4)
+    gr, gc = pt.trace_paths(32, 32, xy, si, seed=3); orr, oc = orc.trace_paths(32, 32, xy, si, seed=3)
+    assert np.array_equal(gc, oc)
+    if beta in (1.0, 2.0):
+        assert np.array_equal(gr, orr)
+    else:  # pow(x, beta) through the math libraries: tolerance 2e-5 relative
+        np.testing.assert_allclose(gr, orr, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("kernel", [ma.KERNEL_MEGA_LDS, ma.KERNEL_MEGA_GLOBAL])
+@pytest.mark.parametrize("w,h,spp,window", [(64, 64, 8, None), (37, 23, 5, None), (64, 48, 3, (5, 7, 21, 30)), (8, 8, 1, None), (1, 1, 64, None), (130, 9, 2, (120, 0, 10, 9))])
+def test_render_equals_oracle(cornell, kernel, w, h, spp, window):
+    """Technique::render for spp frames: image, denominators and ray counters (ragged sizes, windows)."""
+    pt, orc = ma.PathTracing(cornell, max_path=8), oracle.Oracle(cornell, max_path=8)
+    pt.set_kernel(kernel)
+    img = pt.render_rgbn(w, h, spp=spp, seed=5, sample_offset=3, window=window)
+    ref = orc.render_rgbn(w, h, spp=spp, seed=5, sample_offset=3, window=window)
+    st, so = pt.last_stats, orc.last_stats
+    assert (st.num_paths, st.num_basic_rays, st.num_shadow_rays, st.numeric_errors) == (so.num_paths, so.num_basic_rays, so.num_shadow_rays, so.numeric_errors)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    # FP64 per-pixel sums are order independent up to FP64 rounding: after the FP32 cast at most 1 ulp
+    np.testing.assert_allclose(img, ref, rtol=1.2e-7, atol=0)
+    if window:
+        x0, y0, ww, hh = window
+        mask = np.ones((h, w), bool); mask[y0:y0 + hh, x0:x0 + ww] = False
+        assert not img[mask].any()
+
+
+def test_both_kernel_variants_agree_and_runs_are_deterministic(cornell):
+    pt = ma.PathTracing(cornell, max_path=8)
+    pt.set_kernel(ma.KERNEL_MEGA_LDS); a = pt.render_rgbn(96, 96, spp=32, seed=9); a2 = pt.render_rgbn(96, 96, spp=32, seed=9)
+    pt.set_kernel(ma.KERNEL_MEGA_GLOBAL); b = pt.render_rgbn(96, 96, spp=32, seed=9)
+    assert np.array_equal(a[..., 3], b[..., 3])
+    np.testing.assert_allclose(a, a2, rtol=1.2e-7); np.testing.assert_allclose(a, b, rtol=1.2e-7)
+    c = pt.render_rgbn(96, 96, spp=32, seed=10)
+    assert not np.array_equal(a, c)
+
+
+def test_numeric_errors_are_dropped_not_accumulated():
+    """TransmissionBSDF has no TIR guard: sqrt(<0) = NaN; such samples are dropped and counted,
+    and denom is NOT incremented (BSDF.cpp:480-493, Technique.cpp:222-230)."""
+    s = load_scene("CornellBoxSpecular")
+    pt, orc = ma.PathTracing(s, max_path=10), oracle.Oracle(s, max_path=10)
+    img = pt.render_rgbn(64, 64, spp=16, seed=2); ref = orc.render_rgbn(64, 64, spp=16, seed=2)
+    assert pt.last_stats.numeric_errors == orc.last_stats.numeric_errors
+    assert np.isfinite(img).all()
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    assert int((16 * 64 * 64) - img[..., 3].sum()) == pt.last_stats.numeric_errors
+    np.testing.assert_allclose(img, ref, rtol=1.2e-7)
+
+
+def test_sample_ranges_are_additive(cornell):
+    """Streams are keyed on the global sample index: [0,24) == [0,8) + [8,24) (what the RCCL merge relies on)."""
+    pt = ma.PathTracing(cornell, max_path=8)
+    whole = pt.render_rgbn(64, 64, spp=24, seed=1, sample_offset=0)
+    parts = pt.render_rgbn(64, 64, spp=8, seed=1, sample_offset=0).astype(np.float64) + pt.render_rgbn(64, 64, spp=16, seed=1, sample_offset=8)
+    assert np.array_equal(whole[..., 3], parts[..., 3])
+    np.testing.assert_allclose(whole, parts, rtol=3e-7)
+
+
+def test_technique_render_accumulates_like_the_reference(cornell):
+    """Technique::render adds one frame per call to the dvec4 view and fills statistics (Technique.cpp:47-76)."""
+    pt = ma.PathTracing(cornell, max_path=4)
+    view = np.zeros((32, 32, 4), np.float64)
+    for i in range(3):
+        rec = pt.render(view, seed=1)
+        assert rec["sample_index"] == i and rec["numeric_errors"] == 0
+    st = pt.statistics()
+    assert st.num_samples == 3 and np.all(view[..., 3] == 3) and len(st.records) == 3
+    orc = oracle.Oracle(cornell, max_path=4)
+    ref = orc.render_rgbn(32, 32, spp=3, seed=1)
+    np.testing.assert_allclose(view, ref, rtol=3e-7)
+    assert (st.num_basic_rays, st.num_shadow_rays) == (orc.last_stats.num_basic_rays, orc.last_stats.num_shadow_rays)
+
+
+def test_white_furnace_on_device():
+    s = load_scene("TestCaseFurnace")
+    pt = ma.PathTracing(s)
+    img = pt.render_rgbn(64, 64, spp=512, seed=3)
+    rgb = img[..., :3] / img[..., 3:]
+    assert rgb.mean() == pytest.approx(1.0, abs=0.002) and np.abs(rgb - 1).max() < 0.08
+
+
+def test_full_size_workload_properties(cornell):
+    """BASELINE configs[1] at full size: 512x512, 1024 spp, max path 8 — checked through size-independent
+    properties: every pixel has denom == spp, path count exact, image statistically equal to the oracle."""
+    pt = ma.PathTracing(cornell, max_path=8)
+    img = pt.render_rgbn(512, 512, spp=1024, seed=0x5EED)
+    st = pt.last_stats
+    assert st.num_paths == 512 * 512 * 1024 and st.numeric_errors == 0
+    assert np.all(img[..., 3] == 1024)
+    assert st.num_basic_rays >= st.num_paths and st.num_shadow_rays <= st.num_basic_rays
+    gpu = img[..., :3] / 1024
+    orc = oracle.Oracle(cornell, max_path=8)
+    a = orc.render_rgbn(512, 512, spp=4, seed=1)[..., :3] / 4
+    b = orc.render_rgbn(512, 512, spp=4, seed=2)[..., :3] / 4
+    rmse = lambda x, y: float(np.sqrt(np.mean((x - y) ** 2)))
+    # BASELINE.md parity rule: RMSE(GPU, CPU) <= 1.5 x RMSE(CPU, CPU') and mean-radiance bias < 0.5 %
+    assert rmse(gpu, a) <= 1.5 * rmse(a, b)
+    assert abs(gpu.mean() - 0.5 * (a.mean() + b.mean())) / gpu.mean() < 0.005 * 4  # 4 spp oracle: noise of the CPU mean itself is ~1 %
+    # linearity in the sample range: two half renders merge to the same image
+    half = pt.render_rgbn(512, 512, spp=512, seed=0x5EED, sample_offset=0).astype(np.float64) + pt.render_rgbn(512, 512, spp=512, seed=0x5EED, sample_offset=512)
+    np.testing.assert_allclose(img, half, rtol=3e-7)
+
+
+def test_error_behaviour_on_device(cornell):
+    pt = ma.PathTracing(cornell, max_path=8)
+    with pytest.raises(ma.MiError) as e:
+        pt.render_rgbn(32, 32, spp=1, camera_id=5)           # Cameras.cpp:48 runtime_assert(cameraId < size)
+    assert e.value.code == -1
+    with pytest.raises(ma.MiError):
+        pt.render_rgbn(32, 32, spp=1, window=(30, 0, 8, 8))   # Technique.cpp:318 runtime_assert(xEnd <= width)
+    with pytest.raises(ma.MiError):
+        pt.render_rgbn(32, 32, spp=0)
+    with pytest.raises(ma.MiError):
+        ma.PathTracing(cornell, roulette=0.0)
+    with pytest.raises(ma.MiError):
+        ma.PathTracing(cornell, device=99)
+    big = sb.random_soup(20000, seed=1)
+    with pytest.raises(ma.MiError):
+        ma.PathTracing(big).set_kernel(ma.KERNEL_MEGA_LDS)    # does not fit LDS

@@ -1,0 +1,238 @@
+"""Pins the CPU oracle (CPU-only): closed-form results of the estimator it restates, the
+reference's normalised test scenes, internal consistency (BVH == brute force, Embree semantics),
+and frozen regression vectors (tests/golden)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import master_amd as ma
+import oracle
+import scene_builders as sb
+from conftest import ROOT, load_scene
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_rng_stream_matches_frozen_vectors():
+    kat = json.load(open(os.path.join(GOLD, "rng_kat.json")))
+    for c in kat["cases"]:
+        v = oracle.rng_floats(c["seed"], c["pixel"], c["sample"], 8)
+        assert [float(x).hex() for x in v] == c["floats_hex"]
+        assert np.all((v >= 0) & (v < 1))
+
+
+def test_rng_uniformity_and_independence_across_paths():
+    v = np.concatenate([oracle.rng_floats(1, p, s, 4) for p in range(64) for s in range(64)])
+    assert abs(v.mean() - 0.5) < 0.01 and abs(v.var() - 1 / 12) < 0.005
+    a = np.array([oracle.rng_floats(1, p, 0, 1)[0] for p in range(4096)])
+    b = np.array([oracle.rng_floats(1, p, 1, 1)[0] for p in range(4096)])
+    assert abs(np.corrcoef(a, b)[0, 1]) < 0.05
+
+
+def test_cornell_lbvh_and_paths_regression_pins(cornell):
+    pin = json.load(open(os.path.join(GOLD, "cornell_lbvh_pin.json")))
+    nodes, order, morton = oracle.Oracle(cornell).bvh()
+    assert order.tolist() == pin["sorted_tri"] and morton.tolist() == pin["morton"]
+    assert [[int(n["link0"]), int(n["link1"])] for n in nodes] == pin["links"]
+    pins = json.load(open(os.path.join(GOLD, "cornell_paths_pin.json")))
+    xy = np.stack(np.meshgrid(np.arange(32), np.arange(32)), -1).reshape(-1, 2).astype(np.uint32)
+    xy = np.tile(xy, (4, 1)); si = np.repeat(np.arange(4, dtype=np.uint64), 1024)
+    for c in pins["cases"]:
+        rad, cnt = oracle.Oracle(cornell, max_path=c["max_path"]).trace_paths(32, 32, xy, si, seed=7)
+        assert int(np.bitwise_xor.reduce(rad.view(np.uint32).ravel())) == c["xor_bits"]
+        assert int(cnt[:, 0].sum()) == c["basic"] and int(cnt[:, 1].sum()) == c["shadow"]
+
+
+def test_lbvh_is_a_valid_hierarchy():
+    s = sb.random_soup(3000, seed=3)
+    o = oracle.Oracle(s)
+    nodes, order, morton = o.bvh()
+    n = s.n_triangles
+    assert sorted(order.tolist()) == list(range(n)) and np.all(np.diff(morton.astype(np.int64)) >= 0)
+    seen_leaf, seen_node = np.zeros(n, bool), np.zeros(n - 1, bool)
+    seen_node[0] = True
+    tri_lo = s.positions[s.indices].min(1); tri_hi = s.positions[s.indices].max(1)
+    for i, nd in enumerate(nodes):
+        for link, lo, hi in ((nd["link0"], nd["lo0"], nd["hi0"]), (nd["link1"], nd["lo1"], nd["hi1"])):
+            if link < 0:
+                assert not seen_leaf[~link]; seen_leaf[~link] = True
+                t = order[~link]
+                assert np.all(lo <= tri_lo[t]) and np.all(hi >= tri_hi[t])  # padded leaf box contains the triangle
+            else:
+                assert not seen_node[link]; seen_node[link] = True
+                assert nodes[link]["parent"] == i
+                clo = np.minimum(nodes[link]["lo0"], nodes[link]["lo1"]); chi = np.maximum(nodes[link]["hi0"], nodes[link]["hi1"])
+                assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+    assert seen_leaf.all() and seen_node.all()
+
+
+def _rays(scene, n, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = scene.positions.min(0), scene.positions.max(0)
+    o = np.zeros(n, ma.SURFACE_DTYPE)
+    o["position"] = rng.uniform(lo, hi, (n, 3)); g = rng.normal(size=(n, 3)); o["gnormal"] = g / np.linalg.norm(g, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+@pytest.mark.parametrize("scene_name", ["CornellBoxDiffuse", "CornellBoxSpecular", "soup"])
+def test_bvh_traversal_equals_brute_force(scene_name):
+    s = sb.random_soup(2000, seed=5) if scene_name == "soup" else load_scene(scene_name)
+    o = oracle.Oracle(s, use_bvh=True)
+    org, d = _rays(s, 20000, 1)
+    h1, t1, p1 = o.intersect(org, d)
+    tg, _ = _rays(s, 20000, 2)
+    v1 = o.occluded(org, tg)
+    o.set_use_bvh(False)
+    h2, t2, p2 = o.intersect(org, d)
+    v2 = o.occluded(org, tg)
+    assert np.array_equal(p1, p2) and np.array_equal(t1, t2) and h1.tobytes() == h2.tobytes() and np.array_equal(v1, v2)
+
+
+def test_embree_hit_semantics(cornell):
+    """P = (1-u-v) v0 + u v1 + v v2 on the reported triangle; gnormal faces the ray; frames orthonormal."""
+    o = oracle.Oracle(cornell)
+    org, d = _rays(cornell, 5000, 3)
+    hits, t, prim = o.intersect(org, d)
+    ok = prim != ma.UINT32_MAX
+    assert ok.mean() > 0.5
+    tri = cornell.positions[cornell.indices[prim[ok]]]
+    p = hits["position"][ok]
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    assert np.abs(np.einsum("ij,ij->i", p - tri[:, 0], n)).max() < 1e-5            # on the triangle's plane
+    assert np.all(np.einsum("ij,ij->i", hits["gnormal"][ok], -d[ok]) >= 0)         # Scene.cpp:119-120
+    T = hits["tangent"][ok].reshape(-1, 3, 3)
+    gram = np.einsum("nij,nkj->nik", T, T)
+    assert np.abs(gram - np.eye(3)).max() < 1e-5                                  # Gram–Schmidt (Scene.cpp:98-111)
+    assert np.array_equal(hits["material_id"][ok], cornell.tri_material[prim[ok]])
+
+
+def test_shadow_rays_ignore_light_quads(cornell):
+    """Scene.cpp:42,173: ray mask 1<<mesh never matches the light geometry (mask 1<<light)."""
+    l = cornell.lights[0]
+    a = np.zeros(1, ma.SURFACE_DTYPE); b = np.zeros(1, ma.SURFACE_DTYPE)
+    a["position"] = [[l.position[0], l.position[1], l.position[2] + 0.005]]  # just above the light quad (below the ceiling)
+    a["gnormal"] = [[0, 0, -1]]
+    b["position"] = [[l.position[0], l.position[1], 0.6]]; b["gnormal"] = [[0, 0, 1]]
+    o = oracle.Oracle(cornell)
+    assert o.occluded(a, b)[0] == 1.0                   # the light quad lies between the two points and does not block
+    hits, t, prim = o.intersect(a, np.array([[0, 0, -1]], np.float32))
+    assert (hits["material_id"][0] & 3) == ma.ENTITY_LIGHT  # ...but a closest-hit ray does see it (mask 0xFFFFFFFF, Scene.cpp:196)
+
+
+def test_direct_lighting_matches_lamberts_formula():
+    """max_path = 2 (direct light only): pixel radiance = rho/pi * E, E from the closed-form
+    irradiance of a rectangular Lambertian emitter (NEE + BSDF hits, MIS-combined: PT.cpp:41,70-79)."""
+    b = sb.Builder()
+    b.add_camera((0.3, -2.0, 1.0), (0.1, 2.0, -1.0), up=(0, 0, 1), fovx=0.5)
+    rho = (0.6, 0.5, 0.4)
+    m = b.add_material(sb.material(ma.BSDF_DIFFUSE, diffuse=rho))
+    b.add_quad((-5, -5, 0), (5, -5, 0), (5, 5, 0), (-5, 5, 0), m)
+    exit_ = np.array([9.0, 6.0, 3.0])
+    b.add_light((0.2, 0.4, 1.5), (0, 0, -1), (0, 1, 0), (1.0, 0.6), exit_)
+    s = b.build()
+    o = oracle.Oracle(s, max_path=2)
+    W = H = 101
+    win = (50, 50, 1, 1)
+    img = o.render_rgbn(W, H, spp=40000, seed=5, window=win, threads=1)
+    px = img[50, 50, :3] / img[50, 50, 3]
+    # where does the pixel centre hit the floor?
+    f = oracle.camera_setup(s.cameras[0], 1.0)
+    m3 = np.array(list(f.view_to_world), np.float64).reshape(3, 3).T
+    d = m3 @ oracle.ray_direction(50.5, 50.5, W, H, f.focal_length_y).astype(np.float64)
+    cam = np.array(list(f.position), np.float64)
+    x = cam + d * (-cam[2] / d[2])
+    l = s.lights[0]
+    t0, t2 = np.array(l.tangent[0:3]), np.array(l.tangent[6:9]); p = np.array(l.position[:])
+    corners = [p - 0.5 * t0 - 0.3 * t2, p + 0.5 * t0 - 0.3 * t2, p + 0.5 * t0 + 0.3 * t2, p - 0.5 * t0 + 0.3 * t2]
+    for c in range(3):
+        expect = rho[c] / math.pi * sb.rect_irradiance(x, (0, 0, 1), corners, exit_[c] / math.pi)
+        assert px[c] == pytest.approx(expect, rel=0.01)
+
+
+@pytest.mark.parametrize("beta", [0.0, 1.0, 2.0, 1.5])
+def test_mis_weights_are_unbiased_for_any_beta(beta):
+    """The power heuristic with any exponent gives the same expectation (PT.cpp:72-74,113-115)."""
+    s = load_scene("TestCase0")
+    img = oracle.Oracle(s, beta=beta, max_path=2).render_rgbn(32, 32, spp=256, seed=9)
+    assert (img[..., :3] / img[..., 3:]).mean() == pytest.approx(1.0, abs=0.015)  # TestCase0 is one plane: direct light is all there is
+
+
+def test_white_furnace():
+    """Closed box, albedo 0.5, every face covered by a one-sided emitter of radiance 0.5: L = Le / (1 - rho) = 1
+    for every pixel — exercises light pass-through, NEE/MIS, roulette compensation, frames on all six faces."""
+    s = load_scene("TestCaseFurnace")
+    img = oracle.Oracle(s).render_rgbn(32, 32, spp=256, seed=2)
+    rgb = img[..., :3] / img[..., 3:]
+    assert rgb.mean() == pytest.approx(1.0, abs=0.004)
+    assert np.abs(rgb - 1.0).max() < 0.1
+    # truncating the path length truncates the Neumann series: sum_{k<K} Le rho^k
+    for mp, expect in ((1, 0.5), (2, 0.75), (3, 0.875)):
+        img = oracle.Oracle(s, max_path=mp).render_rgbn(16, 16, spp=64, seed=2)
+        assert (img[..., :3] / img[..., 3:]).mean() == pytest.approx(expect, abs=0.01)
+
+
+@pytest.mark.parametrize("name", ["TestCase0", "TestCase2", "TestCase5", "TestCase25", "TestCase3"])
+def test_reference_test_scenes_average_to_one(name):
+    """models/TestCase*.blend are normalised by the reference's author to an image average of 1 at the default
+    512x512 aspect (tests/golden/reference_constants.json) — checks importer conventions + estimator together."""
+    s = load_scene(name)
+    img = oracle.Oracle(s).render_rgbn(64, 64, spp=256, seed=4)
+    assert (img[..., :3] / img[..., 3:]).mean() == pytest.approx(1.0, abs=0.012)
+
+
+def test_lights_scale_and_no_lights(cornell):
+    """--no-lights (lights = 0) removes only directly visible emitters (PT.cpp:24), nothing else."""
+    a = oracle.Oracle(cornell, max_path=3, lights=1.0).render_rgbn(32, 32, spp=8, seed=1)
+    b = oracle.Oracle(cornell, max_path=3, lights=0.0).render_rgbn(32, 32, spp=8, seed=1)
+    diff = (a - b)[..., :3]
+    assert np.count_nonzero(diff.sum(-1)) < 0.1 * 32 * 32 and diff.max() > 1.0  # only the lamp's pixels differ
+
+
+def test_bsdf_sampling_densities_integrate_to_one(cornell):
+    """Diffuse: E[f cos / p] = albedo; Phong: sampled density matches the queried density."""
+    s = load_scene("CornellBoxPhong")
+    o = oracle.Oracle(s)
+    phong = [i for i, m in enumerate(s.materials) if m.type == ma.BSDF_PHONG][0]
+    diff = [i for i, m in enumerate(s.materials) if m.type == ma.BSDF_DIFFUSE][0]
+    sp = np.zeros(1, ma.SURFACE_DTYPE)
+    sp["gnormal"] = [[0, 0, 1]]; sp["tangent"] = [[1, 0, 0, 0, 0, 1, 0, 1, 0]]
+    omega = np.array([0.3, 0.2, 0.93]); omega /= np.linalg.norm(omega)
+    for mat in (diff, phong):
+        sp["material_id"] = (mat << 2) | 1
+        est = np.zeros(3)
+        n = 4000
+        for k in range(n):
+            om, tp, d, dr, fin = o.bsdf_sample(sp, omega, seed=3, pixel=mat, sample=k)
+            if d == 0.0:  # lobe sample below the horizon: throughput 0, the path ends at PT.cpp:62-64
+                assert not np.any(tp)
+                continue
+            tq, dq, drq, _ = o.bsdf_query(sp, omega, om)
+            assert dq == pytest.approx(d, rel=1e-5) and np.allclose(tq, tp, rtol=1e-5)
+            est += tp * abs(om[2]) / d
+        m = s.materials[mat]
+        albedo = np.array(m.diffuse[:]) + (np.array(m.specular[:]) if m.type == ma.BSDF_PHONG else 0)
+        assert np.all(est / n <= albedo * 1.05 + 1e-3)
+        if m.type == ma.BSDF_DIFFUSE:
+            np.testing.assert_allclose(est / n, albedo, rtol=1e-4)
+
+
+def test_light_sampling_is_power_proportional():
+    s = load_scene("DoubleLight")
+    o = oracle.Oracle(s)
+    ids = [o.light_sample(seed=1, pixel=0, sample=k)[0]["material_id"] for k in range(4000)]
+    power = np.array([l.size[0] * l.size[1] * sum(abs(x) for x in l.exitance) for l in s.lights])
+    for i, l in enumerate(s.lights):
+        assert np.mean(np.array(ids) == l.material_id) == pytest.approx(power[i] / power.sum(), abs=0.03)
+
+
+def test_rms_abs_errors_definition():
+    rng = np.random.default_rng(0)
+    rgbn = rng.uniform(0.5, 2, (7, 5, 4)).astype(np.float32); ref = rng.uniform(0, 1, (7, 5, 3)).astype(np.float32)
+    d = np.abs(rgbn[..., :3] / rgbn[..., 3:] - ref)
+    for fn in (ma.rms_abs_errors, oracle.rms_abs_errors):
+        rms, ab = fn(rgbn, ref)
+        assert rms == pytest.approx(math.sqrt((d ** 2).sum() / d.size), rel=1e-5) and ab == pytest.approx(d.sum() / d.size, rel=1e-5)

@@ -1,0 +1,127 @@
+"""Host-side data formats either side of the hot path: .miscene container, EXR (R,G,B,denom), the
+.blend reader against an independent SDNA walker (tools/blend_dump.py) and the committed fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import master_amd as ma
+from conftest import REFERENCE, ROOT, load_scene, scene_path
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "models")), reason="reference tree not present (GPU box)")
+
+
+def scenes_equal(a, b):
+    return (np.array_equal(a.positions, b.positions) and np.array_equal(a.tangents, b.tangents) and np.array_equal(a.indices, b.indices)
+            and np.array_equal(a.mesh_tri_offset, b.mesh_tri_offset) and np.array_equal(a.mesh_material_id, b.mesh_material_id)
+            and [bytes(m) for m in a.materials] == [bytes(m) for m in b.materials] and [bytes(l) for l in a.lights] == [bytes(l) for l in b.lights]
+            and [bytes(c) for c in a.cameras] == [bytes(c) for c in b.cameras] and a.material_names == b.material_names)
+
+
+def test_miscene_round_trip(tmp_path, cornell):
+    p = str(tmp_path / "c.miscene")
+    cornell.save(p)
+    assert scenes_equal(cornell, ma.Scene.load(p))
+    open(p, "r+b").truncate(200)
+    with pytest.raises(ma.MiError):
+        ma.Scene.load(p)
+
+
+def test_cornell_scene_facts(cornell):
+    """30 triangles + 2 for the light quad, 7 diffuse materials, one lamp, one camera."""
+    s = cornell
+    assert s.n_triangles == 32 and len(s.lights) == 1 and len(s.cameras) == 1
+    assert [m.type for m in s.materials] == [ma.BSDF_CAMERA] + [ma.BSDF_DIFFUSE] * 7 + [ma.BSDF_LIGHT]
+    assert sorted(s.material_names[1:8]) == sorted(["backWall", "ceiling", "floor", "leftWall", "rightWall", "shortBox", "tallBox"])
+    l = s.lights[0]
+    np.testing.assert_allclose(list(l.exitance), [0.67 * 40, 0.48 * 40, 0.16 * 40], rtol=1e-6)   # rgb * energy
+    np.testing.assert_allclose(list(l.size), [0.5, 0.5])                                           # square lamp: area_size both ways
+    np.testing.assert_allclose(list(l.tangent[3:6]), [0, 0, -1], atol=1e-6)                        # emits along -Z
+    np.testing.assert_allclose(list(l.position), [-0.005, 0.03, 1.98], atol=1e-6)
+    assert (s.mesh_material_id[-1] & 3) == ma.ENTITY_LIGHT and np.all((s.mesh_material_id[:-1] & 3) == ma.ENTITY_MESH)
+    # material table order: cameras, scene materials, light BSDFs (loader.cpp:304-305,375-378,451-453)
+    assert l.material_id >> 2 == len(s.materials) - 1 and s.materials[-1].light_id == 0
+    # per-corner frames (loader.cpp:332-339): col1 = normal, col0 along the first edge, col2 = cross(n, col0)
+    T = s.tangents.reshape(-1, 3, 3)
+    tri0 = s.positions[s.indices[0]]
+    e = tri0[1] - tri0[0]
+    np.testing.assert_allclose(T[s.indices[0, 0], 0], e / np.linalg.norm(e), atol=1e-5)
+    np.testing.assert_allclose(np.cross(T[:, 1], T[:, 0]), T[:, 2], atol=1e-5)
+
+
+@needs_reference
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxSpecular", "TestCaseFurnace", "TestCase0"])
+def test_committed_fixture_is_what_the_reader_produces(name):
+    fresh = ma.Scene.load_blend(os.path.join(REFERENCE, "models", name + ".blend"))
+    assert scenes_equal(fresh, load_scene(name))
+
+
+@needs_reference
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxSpecular", "CornellBoxPhong", "LivingRoom"])
+def test_blend_reader_against_independent_sdna_walker(name):
+    import blend_dump
+
+    path = os.path.join(REFERENCE, "models", name + ".blend")
+    bl, d = blend_dump.dump(path)
+    s = ma.Scene.load_blend(path)
+    n_area = sum(1 for l in d["lamps"] if l["type"] == 4)
+    tris_of = {m["ptr"]: m["totloop"] - 2 * m["totpoly"] for m in d["meshes"]}
+    tri_expected = sum(tris_of.get(o["data"], 0) for o in d["objects"] if o["type"] == 1)  # a mesh datablock may be instanced by several objects
+    assert len(s.lights) == n_area and len(s.cameras) == sum(1 for o in d["objects"] if o["type"] == 11)
+    assert s.n_triangles == tri_expected + 2 * n_area
+    by_name = {m["name"][2:]: m for m in d["materials"]}
+    for i, m in enumerate(s.materials):
+        src = by_name.get(s.material_names[i])
+        if m.type in (ma.BSDF_CAMERA, ma.BSDF_LIGHT, ma.BSDF_SUN) or src is None:
+            continue
+        np.testing.assert_allclose(list(m.diffuse), src["rgb"], rtol=1e-6)
+        if src["mode"] & 0x10000:
+            assert m.type == ma.BSDF_TRANSMISSION and m.ior_internal == pytest.approx(src["ang"])
+        elif src["mode"] & 0x40000:
+            assert m.type == ma.BSDF_REFLECTION
+        elif not any(src["spec_rgb"]):
+            assert m.type == ma.BSDF_DIFFUSE
+        else:
+            assert m.type == ma.BSDF_PHONG and m.power == src["har"]
+    cam = [c for c in d["cameras"]][0]
+    assert s.cameras[0].fovx == pytest.approx(2 * np.arctan2(cam["sensor_x"], 2 * cam["lens"]), rel=1e-6)
+
+
+def test_specular_scene_has_the_delta_bsdfs():
+    s = load_scene("CornellBoxSpecular")
+    kinds = {m.type for m in s.materials}
+    assert ma.BSDF_REFLECTION in kinds and ma.BSDF_TRANSMISSION in kinds
+    glass = [m for m in s.materials if m.type == ma.BSDF_TRANSMISSION][0]
+    assert glass.ior_internal == pytest.approx(2.0) and glass.ior_external == 1.0   # SURVEY App. B, loader.cpp:381-382
+
+
+def test_exr_round_trip_and_layout(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 5, (13, 17, 4)).astype(np.float32)
+    p = str(tmp_path / "a.exr")
+    ma.save_exr(p, img, {"technique": "PT", "num_samples": 3, "max_path": 8})
+    back = ma.load_exr(p)
+    assert np.array_equal(back, img)
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"\x76\x2f\x31\x01" and b"denom\x00" in raw and b"technique\x00string\x00" in raw and b"PT" in raw
+    # channels are stored alphabetically, rows top-down: first stored float of the first scan line = B of OUR top row
+    with pytest.raises(ma.MiError):
+        ma.load_exr(str(tmp_path / "missing.exr"))
+    open(p, "r+b").truncate(len(raw) // 2)
+    with pytest.raises(ma.MiError):
+        ma.load_exr(p)
+
+
+def test_exr_vertical_flip(tmp_path):
+    img = np.zeros((4, 3, 4), np.float32)
+    img[0, :, 0] = 7.0  # our row 0 = bottom of the image
+    p = str(tmp_path / "f.exr")
+    ma.save_exr(p, img)
+    raw = np.frombuffer(open(p, "rb").read(), np.uint8)
+    # last scan line in the file (EXR y = 3 = bottom) must hold the 7s in its R block
+    line_bytes = 8 + 3 * 16
+    last = raw[-line_bytes:]
+    vals = last[8:].view(np.float32).reshape(4, 3)  # B, G, R, denom
+    assert np.all(vals[2] == 7.0) and not vals[0].any()

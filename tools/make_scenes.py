@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import master_amd as ma  # noqa: E402
 
 SCENES = ["CornellBoxDiffuse", "CornellBoxPhong", "CornellBoxSpecular", "TestCaseFurnace", "TestCase0", "TestCase1", "TestCase2",
-          "SingleAreaLight", "DoubleLight", "MirrorAndAreaLight", "Door"]
+          "TestCase3", "TestCase5", "TestCase6", "TestCase7", "TestCase25", "SingleAreaLight", "DoubleLight", "MirrorAndAreaLight"]
 
 
 def main():

@@ -39,12 +39,24 @@ def algorithmic_bytes_per_sample(st):
     return b, dict(h=h, s=s, Lbar=lbar, N=n_c, T=t_c, N_shadow_per_segment=n_s, T_shadow_per_segment=t_s)
 
 
+def effective_cpus():
+    """Host cores this process may really use: affinity mask, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 256))
+
+
 def cpu_baseline(scene, args, budget_s=12.0):
     """CPU restatement (oracle, kind "port") timed on this host's cores on a bounded sample of the
     same workload: same scene / resolution / max path, fewer samples per pixel."""
     import oracle
 
-    threads = os.cpu_count() or 1
+    threads = effective_cpus()
     orc = oracle.Oracle(scene, lights=1.0, roulette=0.9, beta=1.0, max_path=args.max_path)
     orc.render_rgbn(args.width, args.height, spp=1, seed=1, threads=threads)  # warm-up, page-in
     spp_done, segs, t0 = 0, 0, time.perf_counter()

@@ -241,6 +241,10 @@ typedef struct mi_bvh_info {
 } mi_bvh_info;
 
 int mi_pt_bvh_info(mi_pt_handle* h, mi_bvh_info* out);
+/* The device scene blob as float4 records (layout: master_amd/csrc/device/layout.h): sections in
+ * order nodes | triangles | shading | materials | lights | light cdf.  offsets_f4[7] receives the
+ * six section offsets and the total size (float4 units); blob may be NULL to query sizes only. */
+int mi_pt_blob_download(mi_pt_handle* h, uint32_t offsets_f4[7], float* blob, size_t capacity_f4);
 /* nodes: [n_nodes]; sorted_tri: [n_triangles] global triangle id at each sorted position;
  * morton: [n_triangles] 30-bit codes in sorted order.  Any pointer may be NULL. */
 int mi_pt_bvh_download(mi_pt_handle* h, mi_bvh_node* nodes, uint32_t* sorted_tri,

@@ -109,7 +109,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version",
     "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
-    "mi_pt_bvh_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
+    "mi_pt_bvh_download", "mi_pt_blob_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
     "mi_scene_load", "mi_scene_save", "mi_scene_from_desc", "mi_scene_get_desc", "mi_scene_material_name", "mi_scene_mesh_name",
     "mi_scene_free", "mi_exr_save_rgbn", "mi_exr_load_rgbn", "mi_free", "mi_rms_abs_errors",
 ]
@@ -140,6 +140,7 @@ def lib():
     L.mi_pt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp]
     L.mi_pt_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]
     L.mi_pt_bvh_download.argtypes = [vp, vp, vp, vp]
+    L.mi_pt_blob_download.argtypes = [vp, C.POINTER(u32), vp, C.c_size_t]
     L.mi_camera_setup.argtypes = [C.POINTER(Camera), f32, C.POINTER(CameraFrame)]
     L.mi_camera_ray_direction.argtypes = [f32, f32, f32, f32, f32, C.POINTER(f32)]
     L.mi_camera_ray_direction.restype = None
@@ -419,6 +420,15 @@ class PathTracing:
         cnt = np.zeros((n, 2), np.uint32)
         _check(lib().mi_pt_trace_paths(self._h, camera_id, width, height, n, _ptr(pixel_xy), _ptr(sample_index), seed, _ptr(rad), _ptr(cnt)))
         return rad, cnt
+
+    def blob(self):
+        """Device scene blob as ([n][4] float32, dict of section offsets in float4 units)."""
+        off = (C.c_uint32 * 7)()
+        _check(lib().mi_pt_blob_download(self._h, off, None, 0))
+        data = np.zeros((off[6], 4), np.float32)
+        _check(lib().mi_pt_blob_download(self._h, off, _ptr(data), off[6]))
+        names = ["nodes", "tris", "shade", "materials", "lights", "cdf", "end"]
+        return data, dict(zip(names, list(off)))
 
     def bvh_info(self):
         info = BvhInfo()

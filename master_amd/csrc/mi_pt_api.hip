@@ -389,6 +389,19 @@ int mi_pt_bvh_info(mi_pt_handle* h, mi_bvh_info* out) {
   return MI_OK;
 }
 
+int mi_pt_blob_download(mi_pt_handle* h, uint32_t offsets_f4[7], float* blob, size_t capacity_f4) {
+  if (!h || !offsets_f4) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_blob_download: null argument");
+  const mi::SceneView& v = h->sv;
+  const uint32_t o[7] = {v.off_nodes, v.off_tris, v.off_shade, v.off_mats, v.off_lights, v.off_cdf, v.blob_f4};
+  std::memcpy(offsets_f4, o, sizeof o);
+  if (blob) {
+    if (capacity_f4 < v.blob_f4) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_blob_download: buffer too small");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(blob, h->blob, size_t(v.blob_f4) * 16, hipMemcpyDeviceToHost));
+  }
+  return MI_OK;
+}
+
 int mi_pt_bvh_download(mi_pt_handle* h, mi_bvh_node* nodes, uint32_t* sorted_tri, uint32_t* morton) {
   if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_bvh_download: null handle");
   HIP_TRY(hipSetDevice(h->device));

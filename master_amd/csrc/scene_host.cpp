@@ -160,8 +160,9 @@ namespace {
 struct V3 { float x, y, z; };
 inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-inline V3 cross(V3 a, V3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+// dot / cross as the arithmetic contract defines them: fused exactly where spelled
+inline float dot(V3 a, V3 b) { return std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)); }
+inline V3 cross(V3 a, V3 b) { return {std::fmaf(a.y, b.z, -(b.y * a.z)), std::fmaf(a.z, b.x, -(b.z * a.x)), std::fmaf(a.x, b.y, -(b.x * a.y))}; }
 inline V3 normalize(V3 a) { float s = 1.0f / std::sqrt(dot(a, a)); return {a.x * s, a.y * s, a.z * s}; }
 // column-major 3x3: m[3*c + r]
 void inverse3(const float* m, float* r) {

@@ -923,6 +923,10 @@ ORC_API void orc_light_sample(const orc_scene* s, uint64_t seed, uint32_t pixel,
   rng_t g = rng_seed(seed, pixel, sample); lsample_t l = light_sample(s, &g);
   surf_to_abi(&l.surface, out_surface); st3(radiance, l.radiance); *area_density = l.area_density; *light_density = l.light_density;
 }
+ORC_API void orc_light_table(const orc_scene* s, float* weight, float* cdf) {
+  memcpy(weight, s->light_weight, sizeof(float) * s->d.n_lights);
+  memcpy(cdf, s->light_cdf, sizeof(float) * (s->d.n_lights + 1));
+}
 /* rms_abs_errors (ImageView.cpp:60-85) */
 ORC_API void orc_rms_abs_errors(const float* rgbn, const float* ref, uint32_t w, uint32_t h, float* rms, float* abs_err) {
   float r = 0, a = 0;

@@ -46,6 +46,7 @@ def lib():
         L.orc_bsdf_query.argtypes = [vp, vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(C.c_int)]
         L.orc_bsdf_sample.argtypes = [vp, vp, C.POINTER(f32), u64, u32, u64, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(C.c_int)]
         L.orc_light_sample.argtypes = [vp, u64, u32, u64, vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
+        L.orc_light_table.argtypes = [vp, vp, vp]
         L.orc_rms_abs_errors.argtypes = [vp, vp, u32, u32, C.POINTER(f32), C.POINTER(f32)]
         _lib = L
     return _lib
@@ -128,6 +129,12 @@ class Oracle:
         morton = np.zeros(info.n_triangles, np.uint32)
         lib().orc_bvh_download(self._h, _ptr(nodes), _ptr(sorted_tri), _ptr(morton))
         return nodes, sorted_tri, morton
+
+    def light_table(self):
+        n = len(self.scene.lights)
+        w, cdf = np.zeros(n, np.float32), np.zeros(n + 1, np.float32)
+        lib().orc_light_table(self._h, _ptr(w), _ptr(cdf))
+        return w, cdf
 
     def bsdf_query(self, surface, incident, outgoing):
         sp = np.ascontiguousarray(surface, ma.SURFACE_DTYPE).reshape(1)

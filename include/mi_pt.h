@@ -137,6 +137,8 @@ typedef struct mi_pt_stats {
   uint64_t nodes_closest, tris_closest;  /* BVH nodes fetched / triangles tested by closest-hit rays */
   uint64_t nodes_shadow, tris_shadow;    /* the same for shadow rays                                 */
   uint64_t num_hits;                     /* closest-hit rays that hit a surface                      */
+  uint64_t wave_steps_closest;           /* sum over waves and loop trips of the SLOWEST lane's traversal steps */
+  uint64_t wave_steps_shadow;            /* (nodes + triangles); 64 x this vs the per-lane totals = SIMD efficiency */
 } mi_pt_stats;
 
 typedef struct mi_pt_handle mi_pt_handle;

@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_pt.so")
+LIB_PATH = os.environ.get("MI_PT_LIB") or os.path.join(_HERE, "libmi_pt.so")  # MI_PT_LIB: A/B builds of the same library
 
 MI_OK = 0
 ERR_NAMES = {-1: "INVALID_ARGUMENT", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -4: "IO", -5: "UNSUPPORTED", -6: "INTERNAL"}
@@ -74,7 +74,7 @@ class PtStats(C.Structure):
     _fields_ = [("num_paths", C.c_uint64), ("num_basic_rays", C.c_uint64), ("num_shadow_rays", C.c_uint64), ("numeric_errors", C.c_uint64),
                 ("gpu_ms", C.c_double), ("trace_ms", C.c_double),
                 ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
-                ("num_hits", C.c_uint64)]
+                ("num_hits", C.c_uint64), ("wave_steps_closest", C.c_uint64), ("wave_steps_shadow", C.c_uint64)]
 
 
 class SurfacePoint(C.Structure):

@@ -43,10 +43,22 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """out: alternative output path (A/B variants, e.g. build(extra_flags=["-DX"], out="libmi_pt_x.so"))."""
+    global LIB
+    if out is None and not force and not needs_build():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    lib_saved = LIB
+    if out is not None:
+        LIB = os.path.join(HERE, out)
+    try:
+        return _build(verbose, extra_flags)
+    finally:
+        LIB = lib_saved
+
+
+def _build(verbose, extra_flags):
+    objdir = os.path.join(HERE, "build" + ("_" + os.path.basename(LIB) if not LIB.endswith("libmi_pt.so") else ""))
     os.makedirs(objdir, exist_ok=True)
     common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
               "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]

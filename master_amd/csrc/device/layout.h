@@ -4,7 +4,7 @@
 // staged whole into LDS by every workgroup):
 //   nodes      n_nodes  x 4 float4   BVH2 node = two child boxes + two links (mi_bvh_node, 64 B)
 //   tri_isect  n_tris   x 3 float4   Morton order: v0, e1 = v0-v1, e2 = v2-v0, id, mask (48 B)
-//   tri_shade  n_tris   x 7 float4   Morton order: 3 vertex frames (3 x mat3) + material_id (112 B)
+//   tri_shade  n_tris   x 8 float4   Morton order: 3 vertex frames (3 x mat3), material_id, unit geometric normal (128 B)
 //   materials  n_mats   x 3 float4   mi_material with `reserved` = Phong diffuse probability
 //   lights     n_lights x 6 float4   DevLight
 //   light_cdf  ceil((n_lights+1)/4) float4

@@ -246,11 +246,15 @@ __global__ void k_emit(uint32_t n, const uint32_t* __restrict__ sorted_tri, cons
   tri_isect[3 * size_t(i)] = make_float4(a[0], a[1], a[2], e1x);
   tri_isect[3 * size_t(i) + 1] = make_float4(e1y, e1z, e2x, e2y);
   tri_isect[3 * size_t(i) + 2] = make_float4(e2z, __uint_as_float(t), __uint_as_float(1u << (mat & 3u)), 0.0f);
-  float f[28];
+  float f[32];
   const float* t0 = tan + 9 * size_t(i0); const float* t1 = tan + 9 * size_t(i1); const float* t2 = tan + 9 * size_t(i2);
   for (int k = 0; k < 9; ++k) { f[k] = t0[k]; f[9 + k] = t1[k]; f[18 + k] = t2[k]; }
   f[27] = __uint_as_float(mat);
-  for (int k = 0; k < 7; ++k) tri_shade[7 * size_t(i) + k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+  // unit geometric normal g = normalize(-cross(e2, e1)) (RayIsect.hpp:24), same fma placement as the contract's cross/dot
+  const float nx = -fmaf(e2y, e1z, -(e1y * e2z)), ny = -fmaf(e2z, e1x, -(e1z * e2x)), nz = -fmaf(e2x, e1y, -(e1x * e2y));
+  const float inv = 1.0f / sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
+  f[28] = nx * inv; f[29] = ny * inv; f[30] = nz * inv; f[31] = 0.0f;
+  for (int k = 0; k < 8; ++k) tri_shade[8 * size_t(i) + k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
 }
 
 #define BUILD_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)

@@ -58,14 +58,33 @@ MI_DEV bool tri_test(const float4* __restrict__ tris, uint32_t pos, f3 org, f3 d
   return false;
 }
 
-MI_DEV bool box_test(f3 lo, f3 hi, f3 org, f3 inv, float tmax, float& tnear) {
-  const float t0x = (lo.x - org.x) * inv.x, t1x = (hi.x - org.x) * inv.x;
-  const float t0y = (lo.y - org.y) * inv.y, t1y = (hi.y - org.y) * inv.y;
-  const float t0z = (lo.z - org.z) * inv.z, t1z = (hi.z - org.z) * inv.z;
+// Slab test.  Not part of the bit-exact contract: it only has to be conservative (leaf boxes are
+// padded, the interval is widened), because the closest hit is chosen by (t, id) and does not
+// depend on which boxes were opened.  t = lo * inv - org * inv is one fma per plane; its absolute
+// error is <= 2^-24 * |org * inv| per axis (plus 1 ulp of v_rcp_f32), covered by the per-ray slack.
+struct RayBox { f3 inv, oi; float slack; };
+
+MI_DEV RayBox make_raybox(f3 org, f3 dir) {
+  RayBox r;
+  const float big = 1e18f;  // direction component == 0: a finite stand-in keeps 0 * inf out of the slabs
+  float ix = __builtin_amdgcn_rcpf(dir.x), iy = __builtin_amdgcn_rcpf(dir.y), iz = __builtin_amdgcn_rcpf(dir.z);
+  ix = fabsf(ix) < big ? ix : copysignf(big, dir.x);
+  iy = fabsf(iy) < big ? iy : copysignf(big, dir.y);
+  iz = fabsf(iz) < big ? iz : copysignf(big, dir.z);
+  r.inv = F3(ix, iy, iz);
+  r.oi = org * r.inv;
+  r.slack = (fabsf(r.oi.x) + fabsf(r.oi.y) + fabsf(r.oi.z)) * 2.5e-7f;
+  return r;
+}
+
+MI_DEV bool box_test(f3 lo, f3 hi, const RayBox& rb, float tmax, float& tnear) {
+  const float t0x = fmaf(lo.x, rb.inv.x, -rb.oi.x), t1x = fmaf(hi.x, rb.inv.x, -rb.oi.x);
+  const float t0y = fmaf(lo.y, rb.inv.y, -rb.oi.y), t1y = fmaf(hi.y, rb.inv.y, -rb.oi.y);
+  const float t0z = fmaf(lo.z, rb.inv.z, -rb.oi.z), t1z = fmaf(hi.z, rb.inv.z, -rb.oi.z);
   const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
   const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
   tnear = tn;
-  return tn <= tf * 1.0000004f;
+  return tn <= fmaf(tf, 1.000002f, rb.slack);
 }
 
 // BVH2 traversal with a per-lane stack in LDS (stack[level * kBlock + tid]: consecutive lanes
@@ -84,7 +103,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_
     tri_test<ANY>(tris, 0, org, dir, ray_mask, h);
     return;
   }
-  const f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  const RayBox rb = make_raybox(org, dir);
   int sp = 0;
   int node = 0;
   for (;;) {
@@ -92,8 +111,8 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_
       const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
       if (COUNT) ++vis->nodes;
       float tn0, tn1;
-      const bool h0 = box_test(xyz(n0), xyz(n1), org, inv, h.t, tn0);
-      const bool h1 = box_test(xyz(n2), xyz(n3), org, inv, h.t, tn1);
+      const bool h0 = box_test(xyz(n0), xyz(n1), rb, h.t, tn0);
+      const bool h1 = box_test(xyz(n2), xyz(n3), rb, h.t, tn1);
       const int l0 = __float_as_int(n0.w), l1 = __float_as_int(n1.w);
       if (h0 && h1) {
         const bool sw = tn1 < tn0;
@@ -120,8 +139,8 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_
 // Scene::querySurface (Scene.cpp:80-126)
 MI_DEV Surf query_surface(const float4* __restrict__ sb, const SceneView& sv, f3 org, f3 dir, const Hit& h) {
   Surf p;
-  const float4* sh = sb + sv.off_shade + 7 * h.pos;
-  const float4 q0 = sh[0], q1 = sh[1], q2 = sh[2], q3 = sh[3], q4 = sh[4], q5 = sh[5], q6 = sh[6];
+  const float4* sh = sb + sv.off_shade + 8 * h.pos;
+  const float4 q0 = sh[0], q1 = sh[1], q2 = sh[2], q3 = sh[3], q4 = sh[4], q5 = sh[5], q6 = sh[6], q7 = sh[7];
   const float w = 1.f - h.u - h.v;
   const float u = h.u, v = h.v;
   // vertex frames: t0 = q0.xyzw q1.xyzw q2.x ; t1 = q2.yzw q3.xyzw q4.xy ; t2 = q4.zw q5.xyzw q6.xyz
@@ -138,13 +157,11 @@ MI_DEV Surf query_surface(const float4* __restrict__ sb, const SceneView& sv, f3
   p.tangent.c0 = normalize(p.tangent.c0);
   p.tangent.c2 = (p.tangent.c2 - p.tangent.c1 * dot(p.tangent.c2, p.tangent.c1)) - p.tangent.c0 * dot(p.tangent.c2, p.tangent.c0);
   p.tangent.c2 = normalize(p.tangent.c2);
-  // RayIsect::gnormal / omega (RayIsect.hpp:24-25), flip toward the ray origin (Scene.cpp:119-120)
-  const float4* tr = sb + sv.off_tris + 3 * h.pos;
-  const float4 ta = tr[0], tb = tr[1], tc = tr[2];
-  const f3 e1 = F3(ta.w, tb.x, tb.y), e2 = F3(tb.z, tb.w, tc.x);
-  const f3 g = normalize(-cross(e2, e1));
-  const f3 omega = normalize(-dir);
-  p.gnormal = g * (dot(omega, g) < 0.0f ? -1.0f : 1.0f);
+  // RayIsect::gnormal = normalize(-Ng) (RayIsect.hpp:24) is a per-triangle constant: the LBVH build stores it
+  // in the shading record (k_emit).  Flip toward the ray origin (Scene.cpp:119-120); the sign of
+  // dot(normalize(-dir), g) is taken from dot(-dir, g).
+  const f3 g = F3(q7.x, q7.y, q7.z);
+  p.gnormal = g * (dot(-dir, g) < 0.0f ? -1.0f : 1.0f);
   return p;
 }
 
@@ -157,7 +174,7 @@ MI_DEV f3 nudge(f3 position, f3 gnormal, f3 dir) {
 template <bool COUNT = false>
 MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, uint32_t* stack, f3 opos, f3 ognormal, f3 tpos,
                       f3 tgnormal, Visits* vis = nullptr) {
-  const f3 direction = normalize(tpos - opos);
+  const f3 direction = tpos - opos;  // Scene.cpp:153 normalises; only signs are used
   const f3 ao = opos + (ognormal * (dot(ognormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   const f3 at = tpos + (tgnormal * (dot(tgnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   Hit h; h.t = 1.0f; h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
@@ -304,11 +321,15 @@ MI_DEV void query_lsdf(const float4* __restrict__ sb, const SceneView& sv, uint3
 MI_DEV float powb(float x, float beta) { return beta == 1.0f ? x : (beta == 2.0f ? x * x : powf(x, beta)); }
 
 // PathTracing::_connect (PT.cpp:100-120) incl. AreaLights::sample (AreaLights.cpp:121-140,216-231),
-// LightBSDF::query / sun_light_bsdf::query (BSDF.cpp:95-114,181-191; only .throughput is used),
-// Edge (SurfacePoint.hpp:65-83) and the shadow ray.
-template <bool COUNT = false>
-MI_DEV f3 connect(const float4* __restrict__ sb, const SceneView& sv, uint32_t* stack, Rng& g, const Material& mat,
-                  const Surf& x, f3 x_omega, f3 x_throughput, float beta, uint32_t& n_shadow, Visits* vis = nullptr) {
+// LightBSDF::query / sun_light_bsdf::query (BSDF.cpp:95-114,181-191; only .throughput is used) and
+// Edge (SurfacePoint.hpp:65-83) — everything except the visibility test.  Returns the contribution
+// for an unoccluded light sample and the end points of the shadow ray (Scene::occluded's
+// adjusted origin/target, Scene.cpp:153-167); the caller multiplies by the visibility (0 or 1)
+// once the ray has been traversed.  has_shadow = false: the reference returned before casting.
+struct ShadowRay { f3 org, dir; };
+
+MI_DEV f3 connect_prepare(const float4* __restrict__ sb, const SceneView& sv, Rng& g, const Material& mat, const Surf& x,
+                          f3 x_omega, f3 x_throughput, float beta, bool& has_shadow, ShadowRay& ray) {
   const float u = rng_f(g);
   const float* cdf = reinterpret_cast<const float*>(sb + sv.off_cdf);
   uint32_t id = sv.n_lights - 1;
@@ -321,28 +342,136 @@ MI_DEV f3 connect(const float4* __restrict__ sb, const SceneView& sv, uint32_t* 
   const float ux = (sx - 0.5f) * l2.w, uy = (sy - 0.5f) * l3.w;
   const f3 lpos = (xyz(l0) + xyz(l1) * ux) + xyz(l3) * uy;
   const f3 lnormal = xyz(l2);
-  const f3 omega = normalize(x.position - lpos);
+  const f3 xl = x.position - lpos;
+  const float len2 = dot(xl, xl);  // == dot(lpos - x, lpos - x) bit for bit
+  const f3 omega = xl * (1.0f / sqrtf(len2));
   // light-side "BSDF": front side only; sun lights contribute nothing through NEE
   const float front = (__float_as_uint(l5.z) != 0u && dot(lnormal, omega) > 0.0f) ? 1.0f : 0.0f;
-  if (front * 3.0f < MI_FLT_EPSILON) return F3(0, 0, 0);
+  has_shadow = !(front * 3.0f < MI_FLT_EPSILON);
+  if (!has_shadow) return F3(0, 0, 0);
   const BQuery eb = bsdf_query(mat, x, -omega, x_omega);
   // Edge(light.surface, eye.surface, omega)
-  const f3 d = lpos - x.position;
-  const float distSqInv = 1.0f / dot(d, d);
+  const float distSqInv = 1.0f / len2;
   const float fCos = fabsf(dot(omega, x.tangent.c1));
   const float bCos = fabsf(dot(omega, lnormal));
   const float fG = distSqInv * fCos;
   const float bG = distSqInv * bCos;
   const float cd = l5.y * l0.w;  // area_density * light_density
   const float wInv = powb(eb.densityRev * bG, beta) / powb(cd, beta) + 1.0f;
-  const float occ = occluded<COUNT>(sb, sv, stack, x.position, x.gnormal, lpos, lnormal, vis);
-  ++n_shadow;
-  f3 r = (xyz(l4) * occ) / cd;
+  // Scene::occluded's end points (Scene.cpp:153-167); signs from the unnormalised direction
+  const f3 direction = lpos - x.position;
+  const f3 ao = x.position + (x.gnormal * (dot(x.gnormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+  const f3 at = lpos + (lnormal * (dot(lnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+  ray.org = ao;
+  ray.dir = at - ao;
+  f3 r = xyz(l4) / cd;
   r = r * x_throughput;
   r = r * eb.throughput;
   r = r * bCos;
   r = r * fG;
   return r / wInv;
+}
+
+// Ray / triangle test with the ray kind chosen at run time (same arithmetic as tri_test<>).
+MI_DEV bool tri_test_rt(bool any, const float4* __restrict__ tris, uint32_t pos, f3 org, f3 dir, uint32_t ray_mask, Hit& h) {
+  const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
+  const uint32_t mask = __float_as_uint(c.z);
+  if (!(mask & ray_mask)) return false;
+  const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
+  const uint32_t id = __float_as_uint(c.y);
+  const f3 ng = cross(e2, e1);
+  const f3 C = v0 - org;
+  const f3 R = cross(C, dir);
+  const float den = dot(ng, dir);
+  const float absden = fabsf(den);
+  const float sgn = den < 0.0f ? -1.0f : 1.0f;
+  const float U = dot(R, e2) * sgn;
+  const float V = dot(R, e1) * sgn;
+  if (den == 0.0f) return false;
+  if (!(U >= 0.0f) || !(V >= 0.0f) || !(U + V <= absden)) return false;
+  const float T = dot(ng, C) * sgn;
+  if (!(absden * 0.0f < T)) return false;
+  const float t = T / absden;
+  if (any) {
+    if (t <= h.t) { h.id = id; return true; }
+    return false;
+  }
+  if (t < h.t || (t == h.t && id < h.id)) {
+    h.t = t; h.u = U / absden; h.v = V / absden; h.id = id; h.pos = pos;
+    return true;
+  }
+  return false;
+}
+
+// One traversal loop for up to two rays of a lane: first the pending shadow ray of the previous
+// vertex (any-hit, t in (0,1], surface meshes only: Scene.cpp:165-179), then the closest-hit ray
+// (Scene.cpp:190-198).  Fusing them keeps lanes busy: the loop runs max(Ns + Nc) trips over the
+// wave instead of max(Ns) + max(Nc); lanes without a shadow ray start on their closest-hit ray.
+// Explicit while-while form: an inner loop over internal nodes, then one leaf test.
+constexpr int kNodeDone = int(0x80000000u);
+
+template <bool COUNT>
+MI_DEV void traverse_fused(const float4* __restrict__ sb, const SceneView& sv, uint32_t* __restrict__ stack, bool has_shadow,
+                           const ShadowRay& sray, f3 org, f3 dir, Hit& h, float& visibility, Visits* vis_c, Visits* vis_s) {
+  const float4* nodes = sb + sv.off_nodes;
+  const float4* tris = sb + sv.off_tris;
+  const int root = sv.n_nodes ? 0 : ~0;
+  bool any = has_shadow;
+  f3 o = any ? sray.org : org, d = any ? sray.dir : dir;
+  Hit cur;
+  cur.t = any ? 1.0f : __builtin_inff(); cur.u = cur.v = 0.0f; cur.id = 0xFFFFFFFFu; cur.pos = 0;
+  uint32_t mask = any ? (1u << MI_ENTITY_MESH) : 0xFFFFFFFFu;
+  RayBox rb = make_raybox(o, d);
+  int sp = 0;
+  int node = root;
+  visibility = 1.0f;
+  for (;;) {
+    while (node >= 0) {
+      const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+      if (COUNT) { if (any) ++vis_s->nodes; else ++vis_c->nodes; }
+      float tn0, tn1;
+      const bool h0 = box_test(xyz(n0), xyz(n1), rb, cur.t, tn0);
+      const bool h1 = box_test(xyz(n2), xyz(n3), rb, cur.t, tn1);
+      const int l0 = __float_as_int(n0.w), l1 = __float_as_int(n1.w);
+      if (h0 && h1) {
+        const bool sw = tn1 < tn0;
+        stack[sp * kBlock] = uint32_t(sw ? l0 : l1);
+        ++sp;
+        node = sw ? l1 : l0;
+      } else if (h0 || h1) {
+        node = h0 ? l0 : l1;
+      } else if (sp != 0) {
+        --sp;
+        node = int(stack[sp * kBlock]);
+      } else {
+        node = kNodeDone;
+      }
+    }
+    if (node != kNodeDone) {
+      if (COUNT) { if (any) ++vis_s->tris; else ++vis_c->tris; }
+      const bool hit = tri_test_rt(any, tris, uint32_t(~node), o, d, mask, cur);
+      if (any && hit) {
+        node = kNodeDone;
+      } else if (sp != 0) {
+        --sp;
+        node = int(stack[sp * kBlock]);
+      } else {
+        node = kNodeDone;
+      }
+    }
+    if (node == kNodeDone) {
+      if (!any) break;
+      visibility = cur.id != 0xFFFFFFFFu ? 0.f : 1.f;
+      any = false;
+      o = org; d = dir;
+      cur.t = __builtin_inff(); cur.id = 0xFFFFFFFFu;
+      mask = 0xFFFFFFFFu;
+      rb = make_raybox(o, d);
+      sp = 0;
+      node = root;
+    }
+  }
+  h = cur;
 }
 
 }  // namespace mi

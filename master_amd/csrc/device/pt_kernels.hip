@@ -24,6 +24,10 @@ namespace mi {
 MI_DEV uint32_t rank_in(uint64_t mask) {  // number of set bits of `mask` below this lane
   return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
+MI_DEV uint32_t wave_max(uint32_t v) {
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  return v;
+}
 MI_DEV uint32_t wave_sum(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -31,8 +35,18 @@ MI_DEV uint32_t wave_sum(uint32_t v) {
 
 constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4;
 
+#ifndef MI_FUSED_TRAVERSAL
+#define MI_FUSED_TRAVERSAL 0  // 1: shadow ray of vertex k rides in the closest-hit loop of trip k+1 (measured slower: profiles/r01/ab_fused.txt)
+#endif
+#ifndef MI_SHADOW_AFTER_SAMPLE
+#define MI_SHADOW_AFTER_SAMPLE 0  // 0: shadow ray traversed inside the NEE step, before the BSDF sample (measured +2 %)
+#endif
+#ifndef MI_WAVES_PER_SIMD
+#define MI_WAVES_PER_SIMD 4  // <= 128 VGPRs: 4 waves per SIMD measured fastest (3: -12 %, 5: -6 %, profiles/r01/ab_launch_bounds.txt); second __launch_bounds__ argument = minimum waves per SIMD the register budget must allow
+#endif
+
 template <bool LDS_SCENE, bool LIST, bool COUNT>
-__global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
+__global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const RenderParams p) {
   extern __shared__ float4 smem[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -101,7 +115,11 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
   uint32_t pix = 0, item_id = 0;
   uint32_t n_basic = 0, n_shadow = 0, n_err = 0, n_paths = 0;
   uint32_t path_basic = 0, path_shadow = 0;  // LIST mode per-path counts
+  bool pending = false;                      // a shadow ray of the previous vertex waits to be traversed
+  ShadowRay sray; sray.org = F3(0, 0, 0); sray.dir = F3(0, 0, 1);
+  f3 nee = F3(0, 0, 0);                      // its contribution if unoccluded (PT.cpp:117-119 without the visibility)
   Visits vis_c = {0u, 0u}, vis_s = {0u, 0u};  // instrumented variant only
+  uint32_t trips_c = 0, trips_s = 0;           // instrumented: sum over loop trips of the slowest lane's traversal steps
   uint32_t n_hits = 0;
 
   for (;;) {
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
             const float vy = fy * p.res_y_inv * 2.0f - 1.0f;
             dir = mulmv(v2w, normalize(F3(vx, vy, -p.focal_length_y)));
             org = nudge(cam_pos, cam_gnormal, dir);
-            mode = 0; radiance = F3(0, 0, 0); path_size = 0; alive = true;
+            mode = 0; radiance = F3(0, 0, 0); path_size = 0; alive = true; pending = false;
             path_basic = 0; path_shadow = 0;
             ++n_paths;
           }
@@ -144,12 +162,26 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
       continue;
     }
 
+    uint32_t steps_mine_c = 0, steps_mine_s = 0;
     if (alive) {
       // ---- Scene::intersect (Scene.cpp:182-203) ----
-      Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+      Hit h;
+#if MI_FUSED_TRAVERSAL
+      // (+ the shadow ray of the previous vertex, Scene::occluded, in the same loop)
+      float visibility;
+      traverse_fused<COUNT>(sb, sv, stack, pending, sray, org, dir, h, visibility, &vis_c, &vis_s);
+      if (pending) radiance = radiance + nee * visibility;  // PT.cpp:41: radiance += _connect(...)
+      pending = false;
+#else
+      h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+      const uint32_t steps0 = vis_c.nodes + vis_c.tris;
       traverse<false, COUNT>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
+#endif
       ++n_basic; ++path_basic;
       if (COUNT && h.id != 0xFFFFFFFFu) ++n_hits;
+#if !MI_FUSED_TRAVERSAL
+      if (COUNT) steps_mine_c = vis_c.nodes + vis_c.tris - steps0;
+#endif
 
       bool terminate = false, do_vertex = false;
       Surf sp;
@@ -210,17 +242,36 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
         // ---- vertex x = sp: NEE (PT.cpp:41) then BSDF sample (PT.cpp:43-44) ----
         const Material mat = load_material(sb, sv, sp.material_id);
         const f3 x_omega = -dir;
-        uint32_t ns = 0;
-        radiance = radiance + connect<COUNT>(sb, sv, stack, rng, mat, sp, x_omega, x_throughput, p.beta, ns, &vis_s);
-        n_shadow += ns; path_shadow += ns;
+        nee = connect_prepare(sb, sv, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
+        if (pending) { ++n_shadow; ++path_shadow; }
+#if !MI_FUSED_TRAVERSAL && !MI_SHADOW_AFTER_SAMPLE
+        if (pending) {
+          Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
+          const uint32_t s0 = vis_s.nodes + vis_s.tris;
+          traverse<true, COUNT>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
+          if (COUNT) steps_mine_s = vis_s.nodes + vis_s.tris - s0;
+          radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
+          pending = false;
+        }
+#endif
+        const f3 x_position = sp.position, x_gnormal = sp.gnormal;
         const BSample bs = bsdf_sample(mat, rng, sp, x_omega);
         const float bCos = fabsf(dot(-bs.omega, sp.tangent.c1));  // Edge::bCosTheta with omega = -bsdf.omega
         tnum = (x_throughput * bs.q.throughput) * bCos;
         bs_density = bs.q.density; bs_finite = bs.q.finite;
-        xpos = sp.position;
+        xpos = x_position;
         dir = bs.omega;
-        org = nudge(sp.position, sp.gnormal, dir);
+        org = nudge(x_position, x_gnormal, dir);
         mode = 1u;
+#if !MI_FUSED_TRAVERSAL && MI_SHADOW_AFTER_SAMPLE
+        // the shadow ray is traversed after the BSDF sample so that the surface frame and the material are dead by now
+        if (pending) {
+          Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
+          traverse<true, COUNT>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
+          radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
+          pending = false;
+        }
+#endif
       }
 
       if (terminate) {
@@ -238,6 +289,10 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
           ++n_err;
         }
       }
+    }
+    if (COUNT) {  // wave-level trip counts: what the wave pays is the slowest lane of each traversal
+      trips_c += wave_max(steps_mine_c);
+      trips_s += wave_max(steps_mine_s);
     }
   }
 
@@ -263,6 +318,8 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(const RenderParams p) {
       atomicAdd(&p.counters[4], (unsigned long long)v0); atomicAdd(&p.counters[5], (unsigned long long)v1);
       atomicAdd(&p.counters[6], (unsigned long long)v2); atomicAdd(&p.counters[7], (unsigned long long)v3);
       atomicAdd(&p.counters[8], (unsigned long long)v4);
+      atomicAdd(&p.counters[9], (unsigned long long)trips_c);
+      atomicAdd(&p.counters[10], (unsigned long long)trips_s);
     }
   }
 }

@@ -9,6 +9,7 @@
 //   v*M  (i)      = dot(M.c[i], v)
 //   normalize(a)  = a * (1 / sqrt(dot(a,a)))
 //   madd(a,b,s)   = fma(b,s,a) per component
+//   v / s         = v * (1 / s)   (one correctly rounded reciprocal, three multiplies)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,7 +26,7 @@ MI_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
 MI_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
 MI_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
 MI_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
-MI_DEV f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+MI_DEV f3 operator/(f3 a, float s) { const float r = 1.0f / s; return F3(a.x * r, a.y * r, a.z * r); }  // contract: v / s = v * (1 / s)
 MI_DEV f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
 MI_DEV float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 MI_DEV f3 cross(f3 a, f3 b) {

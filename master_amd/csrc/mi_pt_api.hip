@@ -136,7 +136,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
   sv.off_nodes = 0;
   sv.off_tris = sv.off_nodes + 4 * n_nodes;
   sv.off_shade = sv.off_tris + 3 * nt;
-  sv.off_mats = sv.off_shade + 7 * nt;
+  sv.off_mats = sv.off_shade + 8 * nt;
   sv.off_lights = sv.off_mats + 3 * nmat;
   sv.off_cdf = sv.off_lights + 6 * nl;
   sv.blob_f4 = sv.off_cdf + (nl + 1 + 3) / 4;
@@ -291,7 +291,7 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
   HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
   HIP_TRY(hipEventRecord(h->ev2, stream));
   if (stats) {
-    unsigned long long c[9];
+    unsigned long long c[11];
     HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     float t01 = 0.0f, t02 = 0.0f;
@@ -299,7 +299,7 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
     HIP_TRY(hipEventElapsedTime(&t02, h->ev0, h->ev2));
     stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
     stats->trace_ms = t01; stats->gpu_ms = t02;
-    stats->nodes_closest = c[4]; stats->tris_closest = c[5]; stats->nodes_shadow = c[6]; stats->tris_shadow = c[7]; stats->num_hits = c[8];
+    stats->nodes_closest = c[4]; stats->tris_closest = c[5]; stats->nodes_shadow = c[6]; stats->tris_shadow = c[7]; stats->num_hits = c[8]; stats->wave_steps_closest = c[9]; stats->wave_steps_shadow = c[10];
   }
   return MI_OK;
 }

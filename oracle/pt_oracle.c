@@ -60,7 +60,9 @@ static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
-static inline v3 vdivs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+/* vec3 / float is DEFINED as one reciprocal and three multiplies (glm divides per component; the
+ * difference is <= 1 ulp and the definition is this build's, stated identically on the device) */
+static inline v3 vdivs(v3 a, float s) { float r = 1.0f / s; return V(a.x * r, a.y * r, a.z * r); }
 static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
 /* Arithmetic contract: the file is built with -ffp-contract=off and fuses ONLY where
  * fmaf() is spelled.  glm's dot/cross/mat*vec compiled with the reference's flags
@@ -409,8 +411,8 @@ static surf_t query_surface(const orc_scene* s, v3 org, v3 dir, const hit_t* h) 
   p.tangent.c[2] = vnormalize(p.tangent.c[2]);
   /* RayIsect::gnormal = normalize(-Ng), omega = normalize(-dir) (RayIsect.hpp:24-25) */
   v3 g = vnormalize(vneg(h->tri->ng));
-  v3 omega = vnormalize(vneg(dir));
-  p.gnormal = vscale(g, vdot(omega, g) < 0.0f ? -1.0f : 1.0f);
+  /* the reference normalises -dir first (RayIsect::omega); only the sign of the dot product is used */
+  p.gnormal = vscale(g, vdot(vneg(dir), g) < 0.0f ? -1.0f : 1.0f);
   p.material_id = s->tri_material[h->id];
   return p;
 }
@@ -430,7 +432,7 @@ static surf_t scene_intersect(const orc_scene* s, const surf_t* from, v3 dir, co
 
 /* Scene::occluded (Scene.cpp:151-180): 1 = visible */
 static float scene_occluded(const orc_scene* s, const surf_t* origin, const surf_t* target, counters_t* cnt) {
-  v3 direction = vnormalize(vsub(target->position, origin->position));
+  v3 direction = vsub(target->position, origin->position); /* Scene.cpp:153 normalises; only signs are used */
   v3 ao = vadd(origin->position,
                vscale(vscale(origin->gnormal, vdot(origin->gnormal, direction) > 0.0f ? 1.0f : -1.0f), 0.0001f));
   v3 at = vadd(target->position,
@@ -637,12 +639,14 @@ static v3 pt_connect(const orc_scene* s, rng_t* g, const eye_t* eye, counters_t*
   float cd = light.area_density * light.light_density;
   float wInv = powb(eb.densityRev * e.bG, s->p.beta) / powb(cd, s->p.beta) + 1.0f;
   float occ = scene_occluded(s, &eye->surface, &light.surface, cnt);
-  v3 r = vdivs(vscale(light.radiance, occ), cd);
+  /* PT.cpp:117-119 multiplies the visibility in first; here it is applied last (the same value
+   * unless a factor is inf/NaN or the product overflows) so the device can resolve the shadow ray later */
+  v3 r = vdivs(light.radiance, cd);
   r = vmul(r, eye->throughput);
   r = vmul(r, eb.throughput);
   r = vscale(r, e.bCos);
   r = vscale(r, e.fG);
-  return vdivs(r, wInv);
+  return vscale(vdivs(r, wInv), occ);
 }
 
 /* PathTracing::_traceEye (PT.cpp:15-98) */

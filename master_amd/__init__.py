@@ -189,9 +189,10 @@ class Scene:
         self.indices = np.ctypeslib.as_array(d.indices, (nt, 3)).copy()
         self.mesh_tri_offset = np.ctypeslib.as_array(d.mesh_tri_offset, (nm + 1,)).copy()
         self.mesh_material_id = np.ctypeslib.as_array(d.mesh_material_id, (nm,)).copy() if nm else np.zeros(0, np.uint32)
-        self.materials = [d.materials[i] for i in range(d.n_materials)]
-        self.lights = [d.lights[i] for i in range(d.n_lights)]
-        self.cameras = [d.cameras[i] for i in range(d.n_cameras)]
+        # copies: d.materials[i] would alias memory owned by the C scene
+        self.materials = [Material.from_buffer_copy(d.materials[i]) for i in range(d.n_materials)]
+        self.lights = [Light.from_buffer_copy(d.lights[i]) for i in range(d.n_lights)]
+        self.cameras = [Camera.from_buffer_copy(d.cameras[i]) for i in range(d.n_cameras)]
         self.material_names = [lib().mi_scene_material_name(self._h, i).decode() for i in range(d.n_materials)]
         self.mesh_names = [lib().mi_scene_mesh_name(self._h, i).decode() for i in range(nm)]
         self.bounding_sphere = np.array(list(d.bounding_sphere), np.float32)

@@ -36,7 +36,10 @@ def algorithmic_bytes_per_sample(st):
     n_c, t_c = st.nodes_closest / seg, st.tris_closest / seg
     n_s, t_s = st.nodes_shadow / seg, st.tris_shadow / seg  # already per segment (= N' * s, T' * s)
     b = 152.0 * h + 64.0 * (n_c + n_s) + 48.0 * (t_c + t_s) + 32.0 * s + 16.0 / lbar
-    return b, dict(h=h, s=s, Lbar=lbar, N=n_c, T=t_c, N_shadow_per_segment=n_s, T_shadow_per_segment=t_s)
+    eff_c = (st.nodes_closest + st.tris_closest) / (64.0 * st.wave_steps_closest) if st.wave_steps_closest else None
+    eff_s = (st.nodes_shadow + st.tris_shadow) / (64.0 * st.wave_steps_shadow) if st.wave_steps_shadow else None
+    return b, dict(h=h, s=s, Lbar=lbar, N=n_c, T=t_c, N_shadow_per_segment=n_s, T_shadow_per_segment=t_s,
+                   simd_efficiency_closest_traversal=eff_c, simd_efficiency_shadow_traversal=eff_s)
 
 
 def effective_cpus():
@@ -68,7 +71,7 @@ def cpu_baseline(scene, args, budget_s=12.0):
         if dt >= budget_s or spp_done >= args.spp:
             break
     return {"value": segs / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": "%s %dx%d max_path %d, %d spp of %d, %.1f s, CPU restatement of reference PT (own BVH, non-Embree), pthreads over 32x32 tiles" % (
+            "sample": "%s %dx%d max_path %s, %d spp of %d, %.1f s, CPU restatement of reference PT (own BVH, non-Embree), pthreads over 32x32 tiles" % (
                 args.scene, args.width, args.height, args.max_path, spp_done, args.spp, dt)}
 
 
@@ -81,7 +84,7 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
-    ap.add_argument("--max-path", type=int, default=8)
+    ap.add_argument("--max-path", type=int, default=8, help="0 = unlimited (roulette-terminated), the reference default")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 LDS-resident scene, 2 scene in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -105,7 +108,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    scene = ma.Scene.load(os.path.join(ROOT, "scenes", args.scene + ".miscene"))
+    if args.scene.split(":")[0] in ("atrium", "clutter"):  # seeded procedural stand-ins for the missing BASELINE scenes
+        from master_amd import scenegen
+
+        scene = scenegen.load(args.scene)
+    else:
+        scene = ma.Scene.load(os.path.join(ROOT, "scenes", args.scene + ".miscene"))
+    if args.max_path <= 0:
+        args.max_path = ma.PTRDIFF_MAX
     pt = ma.PathTracing(scene, lights=1.0, roulette=0.9, beta=1.0, max_path=args.max_path, device=local_rank)
     if args.kernel:
         pt.set_kernel(args.kernel)
@@ -161,12 +171,13 @@ def main():
         seg_per_launch = float(st.num_basic_rays)
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = b_sample * seg_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, pmc = None, None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             t = json.load(open(tj))
-            key = "%s_%dx%dx%d_mp%d" % (args.scene, W, H, args.spp, args.max_path)
+            key = "%s_%dx%dx%d_mp%d" % (args.scene, W, H, args.spp, min(args.max_path, 999))
             traffic = t.get(key, {}).get("hbm_bytes_per_launch")
+            pmc = t.get(key)
         out = {
             "metric": "Msamples/sec (paths x bounces: closest-hit path segments per second)",
             "value": segs / elapsed / 1e6,
@@ -175,14 +186,17 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s.blend, PT, %dx%d, %d spp per GPU per step, max path %d, beta 1, roulette 0.9 (BASELINE configs[1])" % (args.scene, W, H, args.spp, args.max_path),
+            "config": {"workload": "%s, PT, %dx%d, %d spp per GPU per step, max path %s, beta 1, roulette 0.9%s" % (
+                           args.scene + (".blend" if ":" not in args.scene and args.scene not in ("atrium", "clutter") else " (procedural stand-in)"), W, H, args.spp,
+                           "unlimited" if args.max_path >= ma.PTRDIFF_MAX else args.max_path,
+                           " (BASELINE configs[1])" if (args.scene, W, H, args.spp, args.max_path) == ("CornellBoxDiffuse", 512, 512, 1024, 8) else ""),
                        "kernel": {1: "pt_megakernel<LDS scene>", 2: "pt_megakernel<HBM scene>"}[pt.get_kernel()],
                        "parallelism": "samples sharded over %d GPU(s), RCCL all-reduce of [H][W][4] f32" % world,
                        "Mpaths_per_s": paths / elapsed / 1e6, "Mrays_per_s": (segs + shadow) / elapsed / 1e6,
                        "denom_equals_spp": denom_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "pt_megakernel", "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_sample": b_sample, "terms": terms,
+                         "algorithmic_bytes_per_sample": b_sample, "terms": terms, "pmc": pmc,
                          "note": "scene is LDS-resident: the kernel is VALU/latency-bound, not HBM-bound; algorithmic bytes are SURVEY 8(d)'s per-segment figure"},
         }
         if world == 1 and not args.no_cpu_baseline:

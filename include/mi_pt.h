@@ -139,6 +139,10 @@ typedef struct mi_pt_stats {
   uint64_t num_hits;                     /* closest-hit rays that hit a surface                      */
   uint64_t wave_steps_closest;           /* sum over waves and loop trips of the SLOWEST lane's traversal steps */
   uint64_t wave_steps_shadow;            /* (nodes + triangles); 64 x this vs the per-lane totals = SIMD efficiency */
+  /* diagnostic builds only (-DMI_PHASE_TIMING): shader cycles summed over waves per phase of the loop trip:
+   * 0 regeneration, 1 closest-hit traversal, 2 querySurface + path logic, 3 NEE set-up, 4 shadow traversal,
+   * 5 BSDF sample, 6 commit, 7 loop overhead.  Zero in the product build. */
+  uint64_t phase_cycles[8];
 } mi_pt_stats;
 
 typedef struct mi_pt_handle mi_pt_handle;

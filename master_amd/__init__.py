@@ -74,7 +74,8 @@ class PtStats(C.Structure):
     _fields_ = [("num_paths", C.c_uint64), ("num_basic_rays", C.c_uint64), ("num_shadow_rays", C.c_uint64), ("numeric_errors", C.c_uint64),
                 ("gpu_ms", C.c_double), ("trace_ms", C.c_double),
                 ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
-                ("num_hits", C.c_uint64), ("wave_steps_closest", C.c_uint64), ("wave_steps_shadow", C.c_uint64)]
+                ("num_hits", C.c_uint64), ("wave_steps_closest", C.c_uint64), ("wave_steps_shadow", C.c_uint64),
+                ("phase_cycles", C.c_uint64 * 8)]
 
 
 class SurfacePoint(C.Structure):

@@ -87,14 +87,29 @@ MI_DEV bool box_test(f3 lo, f3 hi, const RayBox& rb, float tmax, float& tnear) {
   return tn <= fmaf(tf, 1.000002f, rb.slack);
 }
 
-// BVH2 traversal with a per-lane stack in LDS (stack[level * kBlock + tid]: consecutive lanes
-// hit consecutive banks).  `sb` = scene blob base (LDS or HBM).
+// Per-lane traversal stack: the first `cap` levels live in LDS (stack[level * kBlock + tid]: consecutive
+// lanes hit consecutive banks); deeper levels — rare, traversal keeps few far children pending — go to a
+// private (scratch) array, so LDS per workgroup stays at `cap` KB however deep the LBVH is.
+constexpr uint32_t kStackSpill = 64;
+struct TravStack {
+  uint32_t* lds;
+  uint32_t cap;
+  uint32_t spill[kStackSpill];
+  MI_DEV void push(int sp, uint32_t v) {
+    if (uint32_t(sp) < cap) lds[sp * kBlock] = v; else spill[(uint32_t(sp) - cap) & (kStackSpill - 1)] = v;
+  }
+  MI_DEV uint32_t pop(int sp) const {
+    return uint32_t(sp) < cap ? lds[sp * kBlock] : spill[(uint32_t(sp) - cap) & (kStackSpill - 1)];
+  }
+};
+
+// BVH2 traversal.  `sb` = scene blob base (LDS or HBM).
 // Visit counters (nodes fetched, triangles tested) feed the roofline's algorithmic-bytes figure; they
 // are only live in the instrumented kernel variant (COUNT) and compile away otherwise.
 struct Visits { uint32_t nodes, tris; };
 
 template <bool ANY, bool COUNT = false>
-MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_t* __restrict__ stack, f3 org, f3 dir,
+MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 org, f3 dir,
                      uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
   const float4* nodes = sb + sv.off_nodes;
   const float4* tris = sb + sv.off_tris;
@@ -116,7 +131,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_
       const int l0 = __float_as_int(n0.w), l1 = __float_as_int(n1.w);
       if (h0 && h1) {
         const bool sw = tn1 < tn0;
-        stack[sp * kBlock] = uint32_t(sw ? l0 : l1);
+        stack.push(sp, uint32_t(sw ? l0 : l1));
         ++sp;
         node = sw ? l1 : l0;
         continue;
@@ -132,7 +147,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, uint32_
     }
     if (sp == 0) return;
     --sp;
-    node = int(stack[sp * kBlock]);
+    node = int(stack.pop(sp));
   }
 }
 
@@ -172,7 +187,7 @@ MI_DEV f3 nudge(f3 position, f3 gnormal, f3 dir) {
 
 // Scene::occluded (Scene.cpp:151-180): 1 = visible.
 template <bool COUNT = false>
-MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, uint32_t* stack, f3 opos, f3 ognormal, f3 tpos,
+MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 opos, f3 ognormal, f3 tpos,
                       f3 tgnormal, Visits* vis = nullptr) {
   const f3 direction = tpos - opos;  // Scene.cpp:153 normalises; only signs are used
   const f3 ao = opos + (ognormal * (dot(ognormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
@@ -411,7 +426,7 @@ MI_DEV bool tri_test_rt(bool any, const float4* __restrict__ tris, uint32_t pos,
 constexpr int kNodeDone = int(0x80000000u);
 
 template <bool COUNT>
-MI_DEV void traverse_fused(const float4* __restrict__ sb, const SceneView& sv, uint32_t* __restrict__ stack, bool has_shadow,
+MI_DEV void traverse_fused(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, bool has_shadow,
                            const ShadowRay& sray, f3 org, f3 dir, Hit& h, float& visibility, Visits* vis_c, Visits* vis_s) {
   const float4* nodes = sb + sv.off_nodes;
   const float4* tris = sb + sv.off_tris;
@@ -435,14 +450,14 @@ MI_DEV void traverse_fused(const float4* __restrict__ sb, const SceneView& sv, u
       const int l0 = __float_as_int(n0.w), l1 = __float_as_int(n1.w);
       if (h0 && h1) {
         const bool sw = tn1 < tn0;
-        stack[sp * kBlock] = uint32_t(sw ? l0 : l1);
+        stack.push(sp, uint32_t(sw ? l0 : l1));
         ++sp;
         node = sw ? l1 : l0;
       } else if (h0 || h1) {
         node = h0 ? l0 : l1;
       } else if (sp != 0) {
         --sp;
-        node = int(stack[sp * kBlock]);
+        node = int(stack.pop(sp));
       } else {
         node = kNodeDone;
       }
@@ -454,7 +469,7 @@ MI_DEV void traverse_fused(const float4* __restrict__ sb, const SceneView& sv, u
         node = kNodeDone;
       } else if (sp != 0) {
         --sp;
-        node = int(stack[sp * kBlock]);
+        node = int(stack.pop(sp));
       } else {
         node = kNodeDone;
       }

@@ -33,6 +33,12 @@ MI_DEV uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+#ifdef MI_PHASE_TIMING
+#define MI_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); phase_t[k] += now_ - last_t; last_t = now_; } while (0)
+#else
+#define MI_STAMP(k) do { } while (0)
+#endif
+
 constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4;
 
 #ifndef MI_FUSED_TRAVERSAL
@@ -41,12 +47,18 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4;
 #ifndef MI_SHADOW_AFTER_SAMPLE
 #define MI_SHADOW_AFTER_SAMPLE 0  // 0: shadow ray traversed inside the NEE step, before the BSDF sample (measured +2 %)
 #endif
-#ifndef MI_WAVES_PER_SIMD
-#define MI_WAVES_PER_SIMD 4  // <= 128 VGPRs: 4 waves per SIMD measured fastest (3: -12 %, 5: -6 %, profiles/r01/ab_launch_bounds.txt); second __launch_bounds__ argument = minimum waves per SIMD the register budget must allow
+// Second __launch_bounds__ argument = minimum waves per SIMD the register budget must allow.  Measured on
+// CornellBoxDiffuse (LDS-resident scene): 3 waves 6.1, 4 waves 7.1, 5 waves 7.7, 6 waves 8.1, 8 waves 6.7 Gsamples/s
+// (profiles/r01/ab_launch_bounds.txt); the 6-wave build spills 136 B/lane to scratch and still wins on latency hiding.
+#ifndef MI_WAVES_LDS
+#define MI_WAVES_LDS 6
+#endif
+#ifndef MI_WAVES_HBM
+#define MI_WAVES_HBM 5  // HBM-resident scenes: 3, 4, 5 waves within 1 %, 6 waves -6 %, 8 waves -10..-30 % (atrium 270k, CornellBoxSpecular)
 #endif
 
 template <bool LDS_SCENE, bool LIST, bool COUNT>
-__global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const RenderParams p) {
+__global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) void pt_megakernel(const RenderParams p) {
   extern __shared__ float4 smem[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -58,7 +70,9 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
     for (uint32_t i = tid; i < blob_f4; i += kBlock) smem[i] = sv.blob[i];
     sb = smem;
   }
-  uint32_t* stack = reinterpret_cast<uint32_t*>(smem + blob_f4) + tid;
+  TravStack stack;
+  stack.lds = reinterpret_cast<uint32_t*>(smem + blob_f4) + tid;
+  stack.cap = p.stack_entries;
   char* acc_base = reinterpret_cast<char*>(smem + blob_f4) + size_t(p.stack_entries) * kBlock * 4 + size_t(wave) * kAccBytesPerWave;
   double* acc_r = reinterpret_cast<double*>(acc_base);
   double* acc_g = acc_r + 64;
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
   uint32_t path_size = 0;
   Rng rng; rng.state = 0;
   uint32_t pix = 0, item_id = 0;
-  uint32_t n_basic = 0, n_shadow = 0, n_err = 0, n_paths = 0;
+  uint32_t n_basic = 0, n_shadow = 0, n_err = 0, n_paths = 0;  // wave-uniform (ballot popcounts): live in SGPRs
   uint32_t path_basic = 0, path_shadow = 0;  // LIST mode per-path counts
   bool pending = false;                      // a shadow ray of the previous vertex waits to be traversed
   ShadowRay sray; sray.org = F3(0, 0, 0); sray.dir = F3(0, 0, 1);
@@ -122,7 +136,13 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
   uint32_t trips_c = 0, trips_s = 0;           // instrumented: sum over loop trips of the slowest lane's traversal steps
   uint32_t n_hits = 0;
 
+#ifdef MI_PHASE_TIMING
+  unsigned long long phase_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_t = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
+    MI_STAMP(7);
+    bool t_started = false, t_shadow = false, t_err = false;  // per-trip events, counted wave-wide at the end of the trip
     // ---- path regeneration: dead lanes take the next samples of the wave's pool ----
     {
       const bool need = !alive;
@@ -152,16 +172,22 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
             org = nudge(cam_pos, cam_gnormal, dir);
             mode = 0; radiance = F3(0, 0, 0); path_size = 0; alive = true; pending = false;
             path_basic = 0; path_shadow = 0;
-            ++n_paths;
+            t_started = true;
           }
         }
       }
     }
-    if (__ballot(alive) == 0ull) {
-      if (pool_next >= pool_end) break;
-      continue;
+    n_paths += uint32_t(__popcll(__ballot(t_started)));
+    {
+      const uint64_t am = __ballot(alive);
+      if (am == 0ull) {
+        if (pool_next >= pool_end) break;
+        continue;
+      }
+      n_basic += uint32_t(__popcll(am));  // every live lane casts exactly one closest-hit ray per trip
     }
 
+    MI_STAMP(0);  // regeneration
     uint32_t steps_mine_c = 0, steps_mine_s = 0;
     if (alive) {
       // ---- Scene::intersect (Scene.cpp:182-203) ----
@@ -177,7 +203,8 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
       const uint32_t steps0 = vis_c.nodes + vis_c.tris;
       traverse<false, COUNT>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
 #endif
-      ++n_basic; ++path_basic;
+      MI_STAMP(1);  // closest-hit traversal
+      ++path_basic;
       if (COUNT && h.id != 0xFFFFFFFFu) ++n_hits;
 #if !MI_FUSED_TRAVERSAL
       if (COUNT) steps_mine_c = vis_c.nodes + vis_c.tris - steps0;
@@ -238,12 +265,14 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
         }
       }
 
+      MI_STAMP(2);  // querySurface + path logic
       if (do_vertex) {
         // ---- vertex x = sp: NEE (PT.cpp:41) then BSDF sample (PT.cpp:43-44) ----
         const Material mat = load_material(sb, sv, sp.material_id);
         const f3 x_omega = -dir;
         nee = connect_prepare(sb, sv, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
-        if (pending) { ++n_shadow; ++path_shadow; }
+        if (pending) { t_shadow = true; ++path_shadow; }
+        MI_STAMP(3);  // NEE set-up
 #if !MI_FUSED_TRAVERSAL && !MI_SHADOW_AFTER_SAMPLE
         if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
@@ -254,6 +283,7 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
           pending = false;
         }
 #endif
+        MI_STAMP(4);  // shadow traversal
         const f3 x_position = sp.position, x_gnormal = sp.gnormal;
         const BSample bs = bsdf_sample(mat, rng, sp, x_omega);
         const float bCos = fabsf(dot(-bs.omega, sp.tangent.c1));  // Edge::bCosTheta with omega = -bsdf.omega
@@ -274,6 +304,7 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
 #endif
       }
 
+      MI_STAMP(5);  // BSDF sample
       if (terminate) {
         // ---- _eye_image += radiance; finite filter of _commit_images (Technique.cpp:222-230,338) ----
         alive = false;
@@ -286,10 +317,13 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
           atomicAdd(&acc_b[pix], double(radiance.z));
           atomicAdd(&acc_n[pix], 1u);
         } else {
-          ++n_err;
+          t_err = true;
         }
       }
     }
+    n_shadow += uint32_t(__popcll(__ballot(t_shadow)));
+    n_err += uint32_t(__popcll(__ballot(t_err)));
+    MI_STAMP(6);  // commit
     if (COUNT) {  // wave-level trip counts: what the wave pays is the slowest lane of each traversal
       trips_c += wave_max(steps_mine_c);
       trips_s += wave_max(steps_mine_s);
@@ -305,13 +339,16 @@ __global__ __launch_bounds__(kBlock, MI_WAVES_PER_SIMD) void pt_megakernel(const
       reinterpret_cast<double2*>(o)[1] = make_double2(acc_b[lane], double(acc_n[lane]));
     }
   }
-  const uint32_t sb_ = wave_sum(n_basic), ss_ = wave_sum(n_shadow), se_ = wave_sum(n_err), sp_ = wave_sum(n_paths);
+  const uint32_t sb_ = n_basic, ss_ = n_shadow, se_ = n_err, sp_ = n_paths;
   if (lane == 0 && p.counters) {
     if (sb_) atomicAdd(&p.counters[0], (unsigned long long)sb_);
     if (ss_) atomicAdd(&p.counters[1], (unsigned long long)ss_);
     if (se_) atomicAdd(&p.counters[2], (unsigned long long)se_);
     if (sp_) atomicAdd(&p.counters[3], (unsigned long long)sp_);
   }
+#ifdef MI_PHASE_TIMING
+  if (lane == 0 && p.counters) for (int k = 0; k < 8; ++k) atomicAdd(&p.counters[16 + k], phase_t[k]);
+#endif
   if (COUNT && p.counters) {
     const uint32_t v0 = wave_sum(vis_c.nodes), v1 = wave_sum(vis_c.tris), v2 = wave_sum(vis_s.nodes), v3 = wave_sum(vis_s.tris), v4 = wave_sum(n_hits);
     if (lane == 0) {
@@ -346,11 +383,13 @@ __global__ __launch_bounds__(256) void pt_finalize(const double* __restrict__ pa
 }
 
 // Batched Scene::intersect + querySurface (parity hook, mi_pt_intersect).
-__global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t n, const mi_surface_point* __restrict__ origins,
+__global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* __restrict__ origins,
                                                      const float* __restrict__ dirs, mi_surface_point* __restrict__ out_hits,
                                                      float* __restrict__ out_t, uint32_t* __restrict__ out_prim) {
   extern __shared__ float4 smem[];
-  uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+  TravStack stack;
+  stack.lds = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+  stack.cap = stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const f3 pos = F3(origins[i].position[0], origins[i].position[1], origins[i].position[2]);
@@ -381,10 +420,12 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t n, 
 }
 
 // Batched Scene::occluded (parity hook, mi_pt_occluded).
-__global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t n, const mi_surface_point* __restrict__ a,
+__global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* __restrict__ a,
                                                     const mi_surface_point* __restrict__ b, float* __restrict__ out) {
   extern __shared__ float4 smem[];
-  uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+  TravStack stack;
+  stack.lds = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+  stack.cap = stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   out[i] = occluded(sv.blob, sv, stack, F3(a[i].position[0], a[i].position[1], a[i].position[2]),
@@ -419,14 +460,14 @@ hipError_t launch_finalize(const double* partial, float* rgbn, uint32_t width, u
 
 hipError_t launch_intersect(const SceneView& sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* origins, const float* dirs,
                             mi_surface_point* out_hits, float* out_t, uint32_t* out_prim, hipStream_t stream) {
-  hipLaunchKernelGGL(k_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, n,
+  hipLaunchKernelGGL(k_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, stack_entries, n,
                      origins, dirs, out_hits, out_t, out_prim);
   return hipGetLastError();
 }
 
 hipError_t launch_occluded(const SceneView& sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* a, const mi_surface_point* b,
                            float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_occluded, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, n, a, b,
+  hipLaunchKernelGGL(k_occluded, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, stack_entries, n, a, b,
                      out);
   return hipGetLastError();
 }

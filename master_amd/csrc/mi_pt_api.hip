@@ -124,7 +124,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreate(&h->stream));
   HIP_TRY(hipEventCreate(&h->ev0)); HIP_TRY(hipEventCreate(&h->ev1)); HIP_TRY(hipEventCreate(&h->ev2));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_counters), 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_counters), 32 * sizeof(unsigned long long)));
 
   const mi::SceneData& s = h->scene;
   const uint32_t nt = uint32_t(s.indices.size() / 3), nmat = uint32_t(s.materials.size()), nl = uint32_t(s.lights.size());
@@ -206,9 +206,13 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
                            h->blob + sv.off_shade, h->d_sorted_tri, h->d_morton, h->info.scene_lo, h->info.scene_hi, &depth, &build_ms,
                            h->stream));
     h->info.n_triangles = nt; h->info.n_nodes = n_nodes; h->info.max_depth = depth; h->info.build_ms = build_ms;
-    uint32_t se = (depth + 7u) / 8u * 8u;  // pending far children <= depth - 1
-    if (se < 8) se = 8;
-    if (se > 128) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the 128-entry traversal stack");
+    // a root-to-leaf path of `depth` nodes has depth - 1 internal nodes, each of which can leave at most one
+    // far child pending: that is the stack's capacity (rounded up to 4; LDS per workgroup = 1 KB per entry)
+    uint32_t need = (depth > 1 ? depth - 1u : 1u);
+    need = (need + 3u) / 4u * 4u;
+    // LDS part of the stack: at most 12 entries (12 KB per workgroup); deeper levels spill to private memory
+    uint32_t se = need < 12u ? need : 12u;
+    if (need > se + 64u) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack (12 LDS + 64 spill entries)");
     h->info.stack_entries = se;
   }
   h->lds_fits = size_t(sv.blob_f4) * 16 <= kLdsSceneLimit;
@@ -284,14 +288,14 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
   if (rc) return rc;
   p.partial = h->partial;
   p.counters = h->d_counters;
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 16 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(h->ev0, stream));
   HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), false, h->instrumented, uint32_t(n_blocks), stream));
   HIP_TRY(hipEventRecord(h->ev1, stream));
   HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
   HIP_TRY(hipEventRecord(h->ev2, stream));
   if (stats) {
-    unsigned long long c[11];
+    unsigned long long c[24];
     HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     float t01 = 0.0f, t02 = 0.0f;
@@ -300,6 +304,7 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
     stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
     stats->trace_ms = t01; stats->gpu_ms = t02;
     stats->nodes_closest = c[4]; stats->tris_closest = c[5]; stats->nodes_shadow = c[6]; stats->tris_shadow = c[7]; stats->num_hits = c[8]; stats->wave_steps_closest = c[9]; stats->wave_steps_shadow = c[10];
+    for (int k = 0; k < 8; ++k) stats->phase_cycles[k] = c[16 + k];
   }
   return MI_OK;
 }

@@ -11,7 +11,7 @@ import pytest
 
 import master_amd as ma
 import oracle
-import scene_builders as sb
+from master_amd import scenegen as sb
 from conftest import load_scene
 
 pytestmark = pytest.mark.gpu
@@ -57,7 +57,7 @@ def test_lbvh_bit_exact(name):
     gn, gs, gm = pt.bvh(); on, os_, om = orc.bvh()
     assert np.array_equal(gm, om) and np.array_equal(gs, os_)
     assert gn.tobytes() == on.tobytes()
-    assert gi.stack_entries >= gi.max_depth - 1
+    assert gi.stack_entries + 64 >= gi.max_depth - 1 and gi.stack_entries <= 12  # LDS part + private-memory spill part
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -209,6 +209,49 @@ def test_full_size_workload_properties(cornell):
     # linearity in the sample range: two half renders merge to the same image
     half = pt.render_rgbn(512, 512, spp=512, seed=0x5EED, sample_offset=0).astype(np.float64) + pt.render_rgbn(512, 512, spp=512, seed=0x5EED, sample_offset=512)
     np.testing.assert_allclose(img, half, rtol=3e-7)
+
+
+def test_large_procedural_scene_deep_tree():
+    """C4' stand-in at test size (~60k triangles, BVH depth > 24, HBM-resident scene, Phong + mirror + glass):
+    LBVH bit-exact, closest hit / shadow rays bit-exact, per-path radiance within the Phong (powf) tolerance."""
+    s = sb.atrium(60000)
+    pt, orc = ma.PathTracing(s), oracle.Oracle(s)
+    assert pt.get_kernel() == ma.KERNEL_MEGA_GLOBAL
+    gi, oi = pt.bvh_info(), orc.bvh_info()
+    assert (gi.n_nodes, gi.max_depth) == (oi.n_nodes, oi.max_depth) and gi.max_depth > 20
+    gn, gs, gm = pt.bvh(); on, os_, om = orc.bvh()
+    assert np.array_equal(gm, om) and np.array_equal(gs, os_) and gn.tobytes() == on.tobytes()
+    o, d = rays(s, 50000, 4)
+    gh, gt, gp = pt.intersect(o, d); oh, ot, op = orc.intersect(o, d)
+    assert np.array_equal(gp, op) and np.array_equal(gt, ot) and gh.tobytes() == oh.tobytes()
+    tg, _ = rays(s, 50000, 5)
+    assert np.array_equal(pt.occluded(o, tg), orc.occluded(o, tg))
+    rng = np.random.default_rng(1); n = 8000
+    xy = np.stack([rng.integers(0, 320, n), rng.integers(0, 180, n)], 1).astype(np.uint32); si = rng.integers(0, 64, n).astype(np.uint64)
+    g, gc = pt.trace_paths(320, 180, xy, si, seed=2); r, rc = orc.trace_paths(320, 180, xy, si, seed=2)
+    same_flow = (gc == rc).all(1)
+    assert same_flow.mean() > 0.99  # a 1-ulp powf difference can flip a roulette / side / visibility test: rare divergent paths
+    close = np.isclose(g, r, rtol=5e-5, atol=1e-6, equal_nan=True).all(1)
+    assert close.mean() > 0.995, close.mean()
+    # image level (BASELINE.md rule): RMSE(GPU, CPU) <= 1.5 x RMSE(CPU, CPU') at equal spp
+    a = orc.render_rgbn(96, 54, spp=8, seed=1)[..., :3] / 8; b = orc.render_rgbn(96, 54, spp=8, seed=2)[..., :3] / 8
+    gimg = pt.render_rgbn(96, 54, spp=8, seed=1)[..., :3] / 8
+    rmse = lambda x, y: float(np.sqrt(np.nanmean((x - y) ** 2)))
+    assert rmse(gimg, a) <= 1.5 * rmse(a, b)
+
+
+def test_phong_scene_within_stated_tolerance():
+    """CornellBoxPhong: every wall is a PhongBSDF (library powf on both sides): tolerance 5e-5 relative per path."""
+    s = load_scene("CornellBoxPhong")
+    pt, orc = ma.PathTracing(s, max_path=6), oracle.Oracle(s, max_path=6)
+    xy, si = grid_paths(40, 40, 4)
+    g, gc = pt.trace_paths(40, 40, xy, si, seed=5); r, rc = orc.trace_paths(40, 40, xy, si, seed=5)
+    same_flow = (gc == rc).all(1)
+    assert same_flow.mean() > 0.995
+    close = np.isclose(g, r, rtol=5e-5, atol=1e-6, equal_nan=True).all(1)
+    assert close.mean() > 0.995, close.mean()
+    img = pt.render_rgbn(64, 64, spp=64, seed=1)[..., :3] / 64; ref = orc.render_rgbn(64, 64, spp=64, seed=1)[..., :3] / 64
+    assert abs(img.mean() - ref.mean()) / ref.mean() < 2e-3
 
 
 def test_error_behaviour_on_device(cornell):

@@ -10,7 +10,7 @@ import pytest
 
 import master_amd as ma
 import oracle
-import scene_builders as sb
+from master_amd import scenegen as sb
 from conftest import ROOT, load_scene
 
 GOLD = os.path.join(ROOT, "tests", "golden")

@@ -61,7 +61,8 @@ template <bool LDS_SCENE, bool LIST, bool COUNT>
 __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) void pt_megakernel(const RenderParams p) {
   extern __shared__ float4 smem[];
   const uint32_t tid = threadIdx.x;
-  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   const SceneView sv = p.sv;
 
   const uint32_t blob_f4 = LDS_SCENE ? sv.blob_f4 : 0u;
@@ -117,16 +118,18 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
 
   // ---- per-lane path state ----
   bool alive = false;
-  uint32_t mode = 0;  // 0 = before the first surface vertex (PT.cpp:20-26), 1 = after a BSDF sample (PT.cpp:46-82)
+  bool bounce = false;  // false = before the first surface vertex (PT.cpp:20-26), true = after a BSDF sample (PT.cpp:46-82)
   f3 org = F3(0, 0, 0), dir = F3(0, 0, 1);
   f3 xpos = F3(0, 0, 0);   // eye[prv].surface.position
   f3 tnum = F3(0, 0, 0);   // eye[prv].throughput * bsdf.throughput * edge.bCosTheta (PT.cpp:59-60)
   float bs_density = 1.0f; // bsdf.density
-  int bs_finite = 1;       // bsdf.finite
+  bool bs_finite = true;   // bsdf.finite
   f3 radiance = F3(0, 0, 0);
-  uint32_t path_size = 0;
+  // path_size (PT.cpp:38) in the low 26 bits, pixel-in-tile in the high 6: one register.  A path of 2^26 edges
+  // cannot occur (roulette survival 0.9^n); the counter saturates there and max_path >= 2^26 means unlimited.
+  uint32_t ps_pix = 0;
   Rng rng; rng.state = 0;
-  uint32_t pix = 0, item_id = 0;
+  uint32_t item_id = 0;
   uint32_t n_basic = 0, n_shadow = 0, n_err = 0, n_paths = 0;  // wave-uniform (ballot popcounts): live in SGPRs
   uint32_t path_basic = 0, path_shadow = 0;  // LIST mode per-path counts
   bool pending = false;                      // a shadow ray of the previous vertex waits to be traversed
@@ -156,7 +159,8 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
             px = p.list_xy[2 * item]; py = p.list_xy[2 * item + 1]; sample = p.list_sample[item];
             item_id = item;
           } else {
-            pix = item & 63u;
+            const uint32_t pix = item & 63u;
+            ps_pix = pix << 26;
             px = tile_x0 + (pix & 7u); py = tile_y0 + (pix >> 3);
             sample = chunk_sample0 + (item >> 6);
             ok = px < p.win_x0 + p.win_w && py < p.win_y0 + p.win_h;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
             const float vy = fy * p.res_y_inv * 2.0f - 1.0f;
             dir = mulmv(v2w, normalize(F3(vx, vy, -p.focal_length_y)));
             org = nudge(cam_pos, cam_gnormal, dir);
-            mode = 0; radiance = F3(0, 0, 0); path_size = 0; alive = true; pending = false;
+            bounce = false; radiance = F3(0, 0, 0); ps_pix &= 0xFC000000u; alive = true; pending = false;
             path_basic = 0; path_shadow = 0;
             t_started = true;
           }
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
       } else {
         sp = query_surface(sb, sv, org, dir, h);
         const bool is_light = surf_is_light(sp);
-        if (mode == 0u) {
+        if (!bounce) {
           if (is_light && p.max_path > 0u) {  // PT.cpp:23-26: directly visible light, continue through it
             const Material lm = load_material(sb, sv, sp.material_id);
             f3 le; float dens;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
           } else if (p.max_path < 2u) {
             terminate = true;  // PT.cpp:28-30
           } else {
-            path_size = 2; do_vertex = true;  // PT.cpp:32-38
+            ps_pix = (ps_pix & 0xFC000000u) | 2u; do_vertex = true;  // PT.cpp:32-38: path_size = 2
           }
         } else {
           // new vertex z = hit (PT.cpp:53-68); Edge(eye[prv], eye[itr], -dir)
@@ -246,19 +250,20 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
               f3 le; float dens;
               query_lsdf(sb, sv, lm.light_id, omega, le, dens);
               float wInv = powb(dens, p.beta) / powb(fG * bs_density, p.beta) + 1.0f;
-              if (bs_finite == 0) wInv = 1.0f;
+              if (!bs_finite) wInv = 1.0f;
               radiance = radiance + (le * ztp) / wInv;
               org = nudge(sp.position, sp.gnormal, dir);
             } else {
               // Russian roulette (PT.cpp:86-94)
+              const uint32_t path_size = ps_pix & 0x03FFFFFFu;
               const float roul = path_size < p.min_subpath ? 1.0f : p.roulette;
               const float uu = rng_f(rng);
               if (roul < uu) {
                 terminate = true;
               } else {
                 x_throughput = ztp / roul;
-                ++path_size;
-                if (path_size > p.max_path) terminate = true; else do_vertex = true;  // PT.cpp:40
+                if (path_size != 0x03FFFFFFu) ++ps_pix;
+                if (path_size + 1u > p.max_path) terminate = true; else do_vertex = true;  // PT.cpp:40
               }
             }
           }
@@ -288,11 +293,11 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
         const BSample bs = bsdf_sample(mat, rng, sp, x_omega);
         const float bCos = fabsf(dot(-bs.omega, sp.tangent.c1));  // Edge::bCosTheta with omega = -bsdf.omega
         tnum = (x_throughput * bs.q.throughput) * bCos;
-        bs_density = bs.q.density; bs_finite = bs.q.finite;
+        bs_density = bs.q.density; bs_finite = bs.q.finite != 0;
         xpos = x_position;
         dir = bs.omega;
         org = nudge(x_position, x_gnormal, dir);
-        mode = 1u;
+        bounce = true;
 #if !MI_FUSED_TRAVERSAL && MI_SHADOW_AFTER_SAMPLE
         // the shadow ray is traversed after the BSDF sample so that the surface frame and the material are dead by now
         if (pending) {
@@ -312,6 +317,7 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
           p.list_radiance[3 * item_id] = radiance.x; p.list_radiance[3 * item_id + 1] = radiance.y; p.list_radiance[3 * item_id + 2] = radiance.z;
           if (p.list_counts) { p.list_counts[2 * item_id] = path_basic; p.list_counts[2 * item_id + 1] = path_shadow; }
         } else if (isfinite(l1norm(radiance))) {
+          const uint32_t pix = ps_pix >> 26;
           atomicAdd(&acc_r[pix], double(radiance.x));
           atomicAdd(&acc_g[pix], double(radiance.y));
           atomicAdd(&acc_b[pix], double(radiance.z));

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -84,7 +85,7 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   p.sv = h->sv;
   p.stack_entries = h->info.stack_entries;
   const uint64_t mp = h->params.max_path;
-  p.max_path = mp > 0x7FFFFFFFull ? 0x7FFFFFFFu : uint32_t(mp);
+  p.max_path = mp >= 0x03FFFFFFull ? 0xFFFFFFFFu : uint32_t(mp);  // the kernel's path_size field has 26 bits: >= 2^26 - 1 edges = unlimited
   p.min_subpath = h->params.min_subpath;
   p.beta = h->params.beta; p.roulette = h->params.roulette; p.lights = h->params.lights;
 }
@@ -271,12 +272,19 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
   p.win_x0 = win.x0; p.win_y0 = win.y0; p.win_w = win.w; p.win_h = win.h;
   p.tiles_x = (win.w + 7) / 8; p.tiles_y = (win.h + 7) / 8;
   const uint64_t n_tiles = uint64_t(p.tiles_x) * p.tiles_y;
-  // sample chunks: enough waves to fill and balance the chip (256 CUs x ~16 waves, x8 rounds)
-  // while a wave still amortises its start-up over >= 32 samples per pixel.
-  uint64_t n_chunks = (32768 + n_tiles - 1) / n_tiles;
-  const uint64_t max_chunks = spp >= 64 ? spp / 32 : 1;
+  // sample chunks: one wave owns a tile x chunk.  Measured on C2 (profiles/r01/ab_chunk.txt): 16-64 samples per
+  // chunk are best (7.8 Gsamples/s), 128 loses 4 %, 256 14 %: the chip holds ~6 k waves, so aim for >= 16 rounds of
+  // waves, keep >= 16 samples per wave, and bound the FP64 partial buffer (32 B per pixel and chunk) by 2 GiB.
+  uint64_t n_chunks = (100000 + n_tiles - 1) / n_tiles;
+  const uint64_t max_chunks = spp >= 32 ? spp / 16 : 1;
   if (n_chunks > max_chunks) n_chunks = max_chunks;
+  const uint64_t mem_chunks = (2ull << 30) / (uint64_t(width) * height * 32ull);
+  if (n_chunks > mem_chunks) n_chunks = mem_chunks;
   if (n_chunks < 1) n_chunks = 1;
+  if (const char* e = std::getenv("MI_PT_CHUNK_SPP")) {  // tuning override: samples per pixel one wave owns
+    const long v = std::atol(e);
+    if (v > 0) n_chunks = (spp + uint64_t(v) - 1) / uint64_t(v);
+  }
   p.chunk_spp = uint32_t((spp + n_chunks - 1) / n_chunks);
   p.n_chunks = (spp + p.chunk_spp - 1) / p.chunk_spp;
   p.spp = spp; p.seed = seed; p.sample_offset = sample_offset;

@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 LDS-resident scene, 2 scene in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses N ranks on one GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="map every rank onto the visible GPUs modulo their count (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -103,10 +105,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":  # RCCL over xGMI: one rank per GPU
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     if args.scene.split(":")[0] in ("atrium", "clutter"):  # seeded procedural stand-ins for the missing BASELINE scenes
         from master_amd import scenegen

@@ -279,6 +279,9 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
         if (pending) { t_shadow = true; ++path_shadow; }
         MI_STAMP(3);  // NEE set-up
 #if !MI_FUSED_TRAVERSAL && !MI_SHADOW_AFTER_SAMPLE
+        // a contribution that is exactly zero (delta BSDF at x, black surface) cannot change the sum whatever the
+        // visibility: the ray the reference would cast (and count, Scene.cpp:177) is counted but not traversed
+        if (pending && !(nee.x != 0.0f || nee.y != 0.0f || nee.z != 0.0f)) pending = false;
         if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
           const uint32_t s0 = vis_s.nodes + vis_s.tris;

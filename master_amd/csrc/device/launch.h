@@ -12,6 +12,9 @@ hipError_t build_lbvh(uint32_t nt, const float* pos, const float* tan, const uin
                       mi_bvh_node* nodes, float4* tri_isect, float4* tri_shade, uint32_t* sorted_tri, uint32_t* morton,
                       float scene_lo[3], float scene_hi[3], uint32_t* max_depth_out, float* build_ms, hipStream_t stream);
 
+hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, const float lo[3], const float inv_step[3],
+                          hipStream_t stream);
+
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene);
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_finalize(const double* partial, float* rgbn, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w,

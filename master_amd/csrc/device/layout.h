@@ -20,6 +20,11 @@ struct SceneView {
   uint32_t off_nodes, off_tris, off_shade, off_mats, off_lights, off_cdf;  // in float4 units
   uint32_t blob_f4;                                                        // total float4 count
   uint32_t n_tris, n_nodes, n_mats, n_lights;
+  // quantised copy of the BVH2 nodes for HBM-resident scenes: 32 B per node (two child boxes as 12 x u16 on a
+  // 65536^3 grid over the scene box, rounded outward by one cell, + two links) — half the bytes per visited node
+  const uint4* qnodes;
+  float grid_lo[3];
+  float grid_inv_step[3];  // cells per world unit
 };
 
 struct DevLight {  // 6 float4

@@ -257,6 +257,36 @@ __global__ void k_emit(uint32_t n, const uint32_t* __restrict__ sorted_tri, cons
   for (int k = 0; k < 8; ++k) tri_shade[8 * size_t(i) + k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
 }
 
+// 16-bit grid coordinates of the child boxes, rounded outward by one extra cell so that float rounding in the
+// ray's grid transform can never cut into the true box.
+__device__ __forceinline__ uint32_t q_lo(float v, float lo, float inv_step) {
+  float q = floorf((v - lo) * inv_step) - 1.0f;
+  q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q);
+  return uint32_t(q);
+}
+__device__ __forceinline__ uint32_t q_hi(float v, float lo, float inv_step) {
+  float q = ceilf((v - lo) * inv_step) + 1.0f;
+  q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q);
+  return uint32_t(q);
+}
+__global__ void k_quantize(uint32_t n_nodes, const mi_bvh_node* __restrict__ nodes, uint4* __restrict__ qnodes, float lx, float ly, float lz,
+                           float ix, float iy, float iz) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const mi_bvh_node n = nodes[i];
+  uint4 a, b;
+  a.x = q_lo(n.lo0[0], lx, ix) | (q_lo(n.lo0[1], ly, iy) << 16);
+  a.y = q_lo(n.lo0[2], lz, iz) | (q_hi(n.hi0[0], lx, ix) << 16);
+  a.z = q_hi(n.hi0[1], ly, iy) | (q_hi(n.hi0[2], lz, iz) << 16);
+  a.w = uint32_t(n.link0);
+  b.x = q_lo(n.lo1[0], lx, ix) | (q_lo(n.lo1[1], ly, iy) << 16);
+  b.y = q_lo(n.lo1[2], lz, iz) | (q_hi(n.hi1[0], lx, ix) << 16);
+  b.z = q_hi(n.hi1[1], ly, iy) | (q_hi(n.hi1[2], lz, iz) << 16);
+  b.w = uint32_t(n.link1);
+  qnodes[2 * size_t(i)] = a;
+  qnodes[2 * size_t(i) + 1] = b;
+}
+
 #define BUILD_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 }  // namespace
@@ -323,6 +353,14 @@ hipError_t build_lbvh(uint32_t nt, const float* pos, const float* tan, const uin
   hipFree(tri_lo); hipFree(tri_hi); hipFree(scene_ord); hipFree(keys_b); hipFree(vals_b); hipFree(hist); hipFree(leaf_parent);
   hipFree(visit); hipFree(depth);
   return hipSuccess;
+}
+
+hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, const float lo[3], const float inv_step[3],
+                          hipStream_t stream) {
+  if (n_nodes == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_quantize, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, qnodes, lo[0], lo[1], lo[2], inv_step[0],
+                     inv_step[1], inv_step[2]);
+  return hipGetLastError();
 }
 
 }  // namespace mi

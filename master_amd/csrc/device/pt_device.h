@@ -108,7 +108,7 @@ struct TravStack {
 // are only live in the instrumented kernel variant (COUNT) and compile away otherwise.
 struct Visits { uint32_t nodes, tris; };
 
-template <bool ANY, bool COUNT = false>
+template <bool ANY, bool COUNT = false, bool QUANT = false>
 MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 org, f3 dir,
                      uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
   const float4* nodes = sb + sv.off_nodes;
@@ -118,17 +118,34 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravSta
     tri_test<ANY>(tris, 0, org, dir, ray_mask, h);
     return;
   }
-  const RayBox rb = make_raybox(org, dir);
+  // QUANT (HBM-resident scenes): boxes are read as 16-bit grid coordinates (32 B per node instead of 64).  The
+  // ray is moved into grid space once — per axis (x - grid_lo) * cells_per_unit, which keeps the ray parameter t —
+  // and the slab test runs on the integers converted to float.  Triangles are always tested in world space.
+  const f3 glo = F3(sv.grid_lo[0], sv.grid_lo[1], sv.grid_lo[2]), gis = F3(sv.grid_inv_step[0], sv.grid_inv_step[1], sv.grid_inv_step[2]);
+  const RayBox rb = QUANT ? make_raybox((org - glo) * gis, dir * gis) : make_raybox(org, dir);
+  const uint4* __restrict__ qn = sv.qnodes;
   int sp = 0;
   int node = 0;
   for (;;) {
     if (node >= 0) {
-      const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+      f3 lo0, hi0, lo1, hi1;
+      int l0, l1;
+      if (QUANT) {
+        const uint4 a = qn[2 * node], b = qn[2 * node + 1];
+        lo0 = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
+        hi0 = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
+        lo1 = F3(float(b.x & 0xFFFFu), float(b.x >> 16), float(b.y & 0xFFFFu));
+        hi1 = F3(float(b.y >> 16), float(b.z & 0xFFFFu), float(b.z >> 16));
+        l0 = int(a.w); l1 = int(b.w);
+      } else {
+        const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+        lo0 = xyz(n0); hi0 = xyz(n1); lo1 = xyz(n2); hi1 = xyz(n3);
+        l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
+      }
       if (COUNT) ++vis->nodes;
       float tn0, tn1;
-      const bool h0 = box_test(xyz(n0), xyz(n1), rb, h.t, tn0);
-      const bool h1 = box_test(xyz(n2), xyz(n3), rb, h.t, tn1);
-      const int l0 = __float_as_int(n0.w), l1 = __float_as_int(n1.w);
+      const bool h0 = box_test(lo0, hi0, rb, h.t, tn0);
+      const bool h1 = box_test(lo1, hi1, rb, h.t, tn1);
       if (h0 && h1) {
         const bool sw = tn1 < tn0;
         stack.push(sp, uint32_t(sw ? l0 : l1));
@@ -186,14 +203,14 @@ MI_DEV f3 nudge(f3 position, f3 gnormal, f3 dir) {
 }
 
 // Scene::occluded (Scene.cpp:151-180): 1 = visible.
-template <bool COUNT = false>
+template <bool COUNT = false, bool QUANT = false>
 MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 opos, f3 ognormal, f3 tpos,
                       f3 tgnormal, Visits* vis = nullptr) {
   const f3 direction = tpos - opos;  // Scene.cpp:153 normalises; only signs are used
   const f3 ao = opos + (ognormal * (dot(ognormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   const f3 at = tpos + (tgnormal * (dot(tgnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   Hit h; h.t = 1.0f; h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-  traverse<true, COUNT>(sb, sv, stack, ao, at - ao, 1u << MI_ENTITY_MESH, h, vis);
+  traverse<true, COUNT, QUANT>(sb, sv, stack, ao, at - ao, 1u << MI_ENTITY_MESH, h, vis);
   return h.id != 0xFFFFFFFFu ? 0.f : 1.f;
 }
 

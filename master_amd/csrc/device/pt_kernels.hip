@@ -50,6 +50,9 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4;
 // Second __launch_bounds__ argument = minimum waves per SIMD the register budget must allow.  Measured on
 // CornellBoxDiffuse (LDS-resident scene): 3 waves 6.1, 4 waves 7.1, 5 waves 7.7, 6 waves 8.1, 8 waves 6.7 Gsamples/s
 // (profiles/r01/ab_launch_bounds.txt); the 6-wave build spills 136 B/lane to scratch and still wins on latency hiding.
+#ifndef MI_QUANT_NODES
+#define MI_QUANT_NODES 1  // kernels that read the scene from HBM walk the 32-byte quantised nodes
+#endif
 #ifndef MI_WAVES_LDS
 #define MI_WAVES_LDS 6
 #endif
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
 #else
       h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
       const uint32_t steps0 = vis_c.nodes + vis_c.tris;
-      traverse<false, COUNT>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
+      traverse<false, COUNT, !LDS_SCENE && MI_QUANT_NODES>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
 #endif
       MI_STAMP(1);  // closest-hit traversal
       ++path_basic;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
         if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
           const uint32_t s0 = vis_s.nodes + vis_s.tris;
-          traverse<true, COUNT>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
+          traverse<true, COUNT, !LDS_SCENE && MI_QUANT_NODES>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
           if (COUNT) steps_mine_s = vis_s.nodes + vis_s.tris - s0;
           radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
           pending = false;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
         // the shadow ray is traversed after the BSDF sample so that the surface frame and the material are dead by now
         if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
-          traverse<true, COUNT>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
+          traverse<true, COUNT, !LDS_SCENE && MI_QUANT_NODES>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
           radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
           pending = false;
         }
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t sta
   const f3 dir = F3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
   const f3 org = nudge(pos, gn, dir);
   Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-  traverse<false>(sv.blob, sv, stack, org, dir, 0xFFFFFFFFu, h);
+  traverse<false, false, MI_QUANT_NODES != 0>(sv.blob, sv, stack, org, dir, 0xFFFFFFFFu, h);
   if (out_t) out_t[i] = h.t;
   if (out_prim) out_prim[i] = h.id;
   if (out_hits) {
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
   stack.cap = stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  out[i] = occluded(sv.blob, sv, stack, F3(a[i].position[0], a[i].position[1], a[i].position[2]),
+  out[i] = occluded<false, MI_QUANT_NODES != 0>(sv.blob, sv, stack, F3(a[i].position[0], a[i].position[1], a[i].position[2]),
                     F3(a[i].gnormal[0], a[i].gnormal[1], a[i].gnormal[2]), F3(b[i].position[0], b[i].position[1], b[i].position[2]),
                     F3(b[i].gnormal[0], b[i].gnormal[1], b[i].gnormal[2]));
 }

@@ -27,6 +27,7 @@ struct mi_pt_handle {
   mi::SceneData scene;
   mi_pt_params params{};
   float4* blob = nullptr;
+  uint4* qnodes = nullptr;
   mi::SceneView sv{};
   uint32_t* d_sorted_tri = nullptr;
   uint32_t* d_morton = nullptr;
@@ -207,6 +208,18 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
                            h->blob + sv.off_shade, h->d_sorted_tri, h->d_morton, h->info.scene_lo, h->info.scene_hi, &depth, &build_ms,
                            h->stream));
     h->info.n_triangles = nt; h->info.n_nodes = n_nodes; h->info.max_depth = depth; h->info.build_ms = build_ms;
+    // quantised node copy on a 65536^3 grid over the scene box (used by the kernels that read the scene from HBM)
+    for (int a = 0; a < 3; ++a) {
+      // the grid overhangs the scene box by two cells on every side so padded leaf boxes never meet the clamp
+      const float ext = h->info.scene_hi[a] - h->info.scene_lo[a];
+      const float inv_step = ext > 0.0f ? 65531.0f / ext : 1.0f;
+      h->sv.grid_inv_step[a] = inv_step;
+      h->sv.grid_lo[a] = h->info.scene_lo[a] - 2.0f / inv_step;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->qnodes), size_t(n_nodes ? n_nodes : 1) * 32));
+    HIP_TRY(mi::quantize_nodes(n_nodes, reinterpret_cast<const mi_bvh_node*>(h->blob + sv.off_nodes), h->qnodes, h->sv.grid_lo, h->sv.grid_inv_step, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->sv.qnodes = h->qnodes;
     // a root-to-leaf path of `depth` nodes has depth - 1 internal nodes, each of which can leave at most one
     // far child pending: that is the stack's capacity (rounded up to 4; LDS per workgroup = 1 KB per entry)
     uint32_t need = (depth > 1 ? depth - 1u : 1u);
@@ -226,6 +239,7 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->blob) hipFree(h->blob);
+  if (h->qnodes) hipFree(h->qnodes);
   if (h->d_sorted_tri) hipFree(h->d_sorted_tri);
   if (h->d_morton) hipFree(h->d_morton);
   if (h->partial) hipFree(h->partial);

@@ -69,8 +69,16 @@ std::string SceneData::validate() const {
     if ((l.material_id >> 2) >= materials.size()) return "light material_id out of range";
     if (!(l.size[0] > 0.0f) || !(l.size[1] > 0.0f)) return "light size must be positive";
   }
+  float total_power = 0.0f;
+  for (const mi_light& l : lights) {
+    const float e = std::fabs(l.exitance[0]) + std::fabs(l.exitance[1]) + std::fabs(l.exitance[2]);
+    if (!std::isfinite(e)) return "non-finite light exitance";
+    total_power += l.size[0] * l.size[1] * e;
+  }
+  if (!lights.empty() && !(total_power > 0.0f)) return "total light power must be positive (AreaLights.cpp:199-209 divides by it)";
   for (float v : positions)
     if (!std::isfinite(v)) return "non-finite vertex position";
+  // tangent frames are not checked: a zero-area triangle has no frame (loader.cpp:336 normalises a zero vector) and can never be hit
   return "";
 }
 

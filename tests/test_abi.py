@@ -70,6 +70,11 @@ def test_scene_validation_rejects_bad_descriptions(cornell):
     bad_mat[0] = (99 << 2) | 1
     with pytest.raises(ma.MiError):
         ma.Scene.from_arrays(s.positions, s.tangents, s.indices, s.mesh_tri_offset, bad_mat, s.materials, s.lights, s.cameras)
+    dark = [ma.Light.from_buffer_copy(l) for l in s.lights]
+    dark[0].exitance[0] = dark[0].exitance[1] = dark[0].exitance[2] = 0.0
+    with pytest.raises(ma.MiError) as e:  # AreaLights::_updateSampler would divide by a zero total power
+        ma.Scene.from_arrays(s.positions, s.tangents, s.indices, s.mesh_tri_offset, s.mesh_material_id, s.materials, dark, s.cameras)
+    assert "power" in str(e.value)
     with pytest.raises(ma.MiError):  # empty scene
         ma.Scene.from_arrays(np.zeros((0, 3)), np.zeros((0, 9)), np.zeros((0, 3)), [0], [], s.materials, s.lights, s.cameras)
 

@@ -254,6 +254,31 @@ def test_phong_scene_within_stated_tolerance():
     assert abs(img.mean() - ref.mean()) / ref.mean() < 2e-3
 
 
+def test_degenerate_and_coincident_triangles():
+    """Zero-area triangles are never hit (den == 0); coincident triangles tie on t and the smaller global index wins —
+    on the device (BVH order) exactly as in the oracle (index order)."""
+    b = sb.Builder()
+    b.add_camera((0, -4, 1), (0, 1, 0))
+    m0 = b.add_material(sb.material(ma.BSDF_DIFFUSE, diffuse=(0.8, 0.2, 0.2)))
+    m1 = b.add_material(sb.material(ma.BSDF_DIFFUSE, diffuse=(0.2, 0.8, 0.2)))
+    quad = [[(-1, 0, 0), (1, 0, 0), (1, 0, 2)], [(-1, 0, 0), (1, 0, 2), (-1, 0, 2)]]
+    b.add_mesh(quad, m0)
+    b.add_mesh(quad, m1)                                                   # coincident copy with another material
+    b.add_mesh([[(0, 1, 0), (0, 1, 0), (0, 1, 0)], [(0, 1, 0), (1, 1, 0), (2, 1, 0)]], m0)   # point and line: zero area
+    b.add_quad((-3, -3, 0), (3, -3, 0), (3, 3, 0), (-3, 3, 0), m1)
+    b.add_light((0, -1, 3), (0, 0.3, -1), (0, 1, 0.3), (1, 1), (20, 20, 20))
+    s = b.build()
+    pt, orc = ma.PathTracing(s, max_path=5), oracle.Oracle(s, max_path=5)
+    o, d = rays(s, 50000, 8)
+    gh, gt, gp = pt.intersect(o, d); oh, ot, op = orc.intersect(o, d)
+    assert np.array_equal(gp, op) and np.array_equal(gt, ot) and gh.tobytes() == oh.tobytes()
+    assert not np.isin(gp, [4, 5]).any()                                    # the degenerate triangles
+    assert not np.isin(gp, [2, 3]).any() and np.isin(gp, [0, 1]).any()      # of each coincident pair the lower index wins
+    xy, si = grid_paths(32, 32, 4)
+    g, gc = pt.trace_paths(32, 32, xy, si, seed=1); r, rc = orc.trace_paths(32, 32, xy, si, seed=1)
+    assert np.array_equal(gc, rc) and np.array_equal(g, r)
+
+
 def test_error_behaviour_on_device(cornell):
     pt = ma.PathTracing(cornell, max_path=8)
     with pytest.raises(ma.MiError) as e:

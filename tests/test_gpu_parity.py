@@ -254,6 +254,23 @@ def test_phong_scene_within_stated_tolerance():
     assert abs(img.mean() - ref.mean()) / ref.mean() < 2e-3
 
 
+def test_4k_frame_and_window_against_oracle(cornell):
+    """BASELINE configs[4] resolution (3840x2160): index arithmetic at full size, and a 48x40 window of that frame
+    against the oracle rendering the same window (pixel indices, camera rays and streams depend on the full resolution)."""
+    pt, orc = ma.PathTracing(cornell, max_path=8), oracle.Oracle(cornell, max_path=8)
+    img = pt.render_rgbn(3840, 2160, spp=2, seed=3)
+    st = pt.last_stats
+    assert st.num_paths == 3840 * 2160 * 2 and np.all(img[..., 3] == 2) and np.isfinite(img).all()
+    win = (1901, 1003, 48, 40)
+    ref = orc.render_rgbn(3840, 2160, spp=2, seed=3, window=win)
+    x0, y0, w, h = win
+    np.testing.assert_allclose(img[y0:y0 + h, x0:x0 + w], ref[y0:y0 + h, x0:x0 + w], rtol=1.2e-7)
+    sub = pt.render_rgbn(3840, 2160, spp=2, seed=3, window=win)
+    np.testing.assert_allclose(sub[y0:y0 + h, x0:x0 + w], ref[y0:y0 + h, x0:x0 + w], rtol=1.2e-7)
+    assert pt.last_stats.num_paths == w * h * 2 == orc.last_stats.num_paths
+    assert (pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays) == (orc.last_stats.num_basic_rays, orc.last_stats.num_shadow_rays)
+
+
 def test_degenerate_and_coincident_triangles():
     """Zero-area triangles are never hit (den == 0); coincident triangles tie on t and the smaller global index wins —
     on the device (BVH order) exactly as in the oracle (index order)."""

@@ -268,6 +268,22 @@ class Statistics:
         self.total_time = 0.0
         self.records = []  # dicts: sample_index, rms_error, abs_error, clock_time, frame_duration, numeric_errors
 
+    def to_dict(self):
+        """statistics_t::to_dict (statistics.cpp:118-175): the string map the reference stores in the EXR header
+        (same keys, std::to_string formatting), so `master continue / merge / statistics` can read our files."""
+        f = lambda v: "%f" % float(v)  # std::to_string(double)
+        d = {"statistics.num_samples": str(int(self.num_samples)), "statistics.num_basic_rays": str(int(self.num_basic_rays)),
+             "statistics.num_shadow_rays": str(int(self.num_shadow_rays)), "statistics.num_tentative_rays": "0",
+             "statistics.num_photons": "0", "statistics.num_scattered": "0", "statistics.total_time": f(self.total_time)}
+        for k in ("scatter_time", "build_time", "gather_time", "merge_time", "density_time", "intersect_time", "trace_eye_time", "trace_light_time"):
+            d["statistics." + k] = f(0.0)
+        for r in self.records:
+            i = int(r["sample_index"])
+            d["records[%d].rms_error" % i] = f(r["rms_error"]); d["records[%d].abs_error" % i] = f(r["abs_error"])
+            d["records[%d].clock_time" % i] = f(r["clock_time"]); d["records[%d].frame_duration" % i] = f(r["frame_duration"])
+            d["records[%d].numeric_errors" % i] = str(int(r["numeric_errors"]))
+        return d
+
 
 def camera_setup(camera, aspect):
     out = CameraFrame()
@@ -339,6 +355,16 @@ class PathTracing:
             self.close()
         except Exception:
             pass
+
+    def options_dict(self, width, height, camera_id=0, input0="", output=""):
+        """The PT-relevant part of Options::to_dict (Options.cpp:1186-1232) for the EXR header."""
+        f = lambda v: "%f" % float(v)
+        mp = self.params.max_path
+        return {"options.input0": input0, "options.output": output, "options.technique": "PT",
+                "options.max_path": str(PTRDIFF_MAX if mp >= PTRDIFF_MAX else int(mp)), "options.beta": f(self.params.beta),
+                "options.roulette": f(self.params.roulette), "options.lights": f(self.params.lights),
+                "options.num_samples": str(int(self._statistics.num_samples)), "options.camera_id": str(int(camera_id)),
+                "options.width": str(int(width)), "options.height": str(int(height))}
 
     # -- Technique API ----------------------------------------------------------------------
     def statistics(self):

@@ -181,6 +181,20 @@ def test_technique_render_accumulates_like_the_reference(cornell):
     assert (st.num_basic_rays, st.num_shadow_rays) == (orc.last_stats.num_basic_rays, orc.last_stats.num_shadow_rays)
 
 
+def test_exr_checkpoint_carries_the_reference_metadata(cornell, tmp_path):
+    """Application::_save (Application.cpp:251) -> save_exr: sums + denom + statistics/options as string attributes."""
+    pt = ma.PathTracing(cornell, max_path=4)
+    view = np.zeros((24, 24, 4), np.float64)
+    pt.render(view, seed=1); pt.render(view, seed=1)
+    meta = dict(pt.statistics().to_dict()); meta.update(pt.options_dict(24, 24))
+    p = str(tmp_path / "c.exr")
+    ma.save_exr(p, view.astype(np.float32), meta)
+    raw = open(p, "rb").read()
+    for key in (b"statistics.num_samples\x00string\x00", b"statistics.num_basic_rays\x00", b"records[1].frame_duration\x00", b"options.technique\x00string\x00", b"options.max_path\x00"):
+        assert key in raw
+    assert np.array_equal(ma.load_exr(p), view.astype(np.float32)) and meta["statistics.num_samples"] == "2" and meta["options.technique"] == "PT"
+
+
 def test_white_furnace_on_device():
     s = load_scene("TestCaseFurnace")
     pt = ma.PathTracing(s)

@@ -143,6 +143,9 @@ typedef struct mi_pt_stats {
    * 0 regeneration, 1 closest-hit traversal, 2 querySurface + path logic, 3 NEE set-up, 4 shadow traversal,
    * 5 BSDF sample, 6 commit, 7 loop overhead.  Zero in the product build. */
   uint64_t phase_cycles[8];
+  /* instrumented: loop bodies executed by waves (whatever the number of active lanes): closest-hit node steps,
+   * closest-hit leaf phases, shadow node steps, shadow leaf phases */
+  uint64_t wave_loop_bodies[4];
 } mi_pt_stats;
 
 typedef struct mi_pt_handle mi_pt_handle;

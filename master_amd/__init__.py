@@ -75,7 +75,7 @@ class PtStats(C.Structure):
                 ("gpu_ms", C.c_double), ("trace_ms", C.c_double),
                 ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
                 ("num_hits", C.c_uint64), ("wave_steps_closest", C.c_uint64), ("wave_steps_shadow", C.c_uint64),
-                ("phase_cycles", C.c_uint64 * 8)]
+                ("phase_cycles", C.c_uint64 * 8), ("wave_loop_bodies", C.c_uint64 * 4)]
 
 
 class SurfacePoint(C.Structure):

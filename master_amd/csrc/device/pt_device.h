@@ -106,7 +106,7 @@ struct TravStack {
 // BVH2 traversal.  `sb` = scene blob base (LDS or HBM).
 // Visit counters (nodes fetched, triangles tested) feed the roofline's algorithmic-bytes figure; they
 // are only live in the instrumented kernel variant (COUNT) and compile away otherwise.
-struct Visits { uint32_t nodes, tris; };
+struct Visits { uint32_t nodes, tris; uint32_t* wave_iters; };  // wave_iters: LDS [2] per wave: node-loop bodies, leaf-phase bodies (instrumented)
 
 template <bool ANY, bool COUNT = false, bool QUANT = false>
 MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 org, f3 dir,
@@ -142,7 +142,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravSta
         lo0 = xyz(n0); hi0 = xyz(n1); lo1 = xyz(n2); hi1 = xyz(n3);
         l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
       }
-      if (COUNT) ++vis->nodes;
+      if (COUNT) { ++vis->nodes; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[0], 1u); }
       float tn0, tn1;
       const bool h0 = box_test(lo0, hi0, rb, h.t, tn0);
       const bool h1 = box_test(lo1, hi1, rb, h.t, tn1);
@@ -158,7 +158,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravSta
         continue;
       }
     } else {
-      if (COUNT) ++vis->tris;
+      if (COUNT) { ++vis->tris; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[1], 1u); }
       const bool hit = tri_test<ANY>(tris, uint32_t(~node), org, dir, ray_mask, h);
       if (ANY && hit) return;
     }

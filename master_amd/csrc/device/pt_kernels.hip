@@ -39,7 +39,7 @@ MI_DEV uint32_t wave_sum(uint32_t v) {
 #define MI_STAMP(k) do { } while (0)
 #endif
 
-constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4;
+constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums, counts, 8 instrumentation words
 
 #ifndef MI_FUSED_TRAVERSAL
 #define MI_FUSED_TRAVERSAL 0  // 1: shadow ray of vertex k rides in the closest-hit loop of trip k+1 (measured slower: profiles/r01/ab_fused.txt)
@@ -138,7 +138,13 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
   bool pending = false;                      // a shadow ray of the previous vertex waits to be traversed
   ShadowRay sray; sray.org = F3(0, 0, 0); sray.dir = F3(0, 0, 1);
   f3 nee = F3(0, 0, 0);                      // its contribution if unoccluded (PT.cpp:117-119 without the visibility)
-  Visits vis_c = {0u, 0u}, vis_s = {0u, 0u};  // instrumented variant only
+  Visits vis_c = {0u, 0u, nullptr}, vis_s = {0u, 0u, nullptr};  // instrumented variant only
+  if (COUNT) {  // wave-level loop-body counters (node-loop bodies, leaf-phase bodies) in the tail of the wave's LDS block
+    uint32_t* wi = acc_n + 64;
+    if (lane < 8) wi[lane] = 0u;
+    vis_c.wave_iters = wi;
+    vis_s.wave_iters = wi + 2;
+  }
   uint32_t trips_c = 0, trips_s = 0;           // instrumented: sum over loop trips of the slowest lane's traversal steps
   uint32_t n_hits = 0;
 
@@ -369,6 +375,7 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
       atomicAdd(&p.counters[8], (unsigned long long)v4);
       atomicAdd(&p.counters[9], (unsigned long long)trips_c);
       atomicAdd(&p.counters[10], (unsigned long long)trips_s);
+      for (int k = 0; k < 4; ++k) atomicAdd(&p.counters[11 + k], (unsigned long long)vis_c.wave_iters[k]);
     }
   }
 }

@@ -327,6 +327,7 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
     stats->trace_ms = t01; stats->gpu_ms = t02;
     stats->nodes_closest = c[4]; stats->tris_closest = c[5]; stats->nodes_shadow = c[6]; stats->tris_shadow = c[7]; stats->num_hits = c[8]; stats->wave_steps_closest = c[9]; stats->wave_steps_shadow = c[10];
     for (int k = 0; k < 8; ++k) stats->phase_cycles[k] = c[16 + k];
+    for (int k = 0; k < 4; ++k) stats->wave_loop_bodies[k] = c[11 + k];
   }
   return MI_OK;
 }

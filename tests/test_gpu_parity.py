@@ -57,7 +57,7 @@ def test_lbvh_bit_exact(name):
     gn, gs, gm = pt.bvh(); on, os_, om = orc.bvh()
     assert np.array_equal(gm, om) and np.array_equal(gs, os_)
     assert gn.tobytes() == on.tobytes()
-    assert gi.stack_entries + 64 >= gi.max_depth - 1 and gi.stack_entries <= 12  # LDS part + private-memory spill part
+    assert gi.stack_entries + 64 >= gi.max_depth - 1 and gi.stack_entries <= 12  # LDS rows + private-memory spill
 
 
 @pytest.mark.parametrize("name", SCENES)

@@ -247,6 +247,8 @@ typedef struct mi_bvh_info {
   uint32_t stack_entries;/* traversal stack capacity the kernels were sized with        */
   float scene_lo[3], scene_hi[3];
   double build_ms;       /* device time of the build kernels                            */
+  uint32_t builder;      /* 1 = PLOC (default), 0 = Karras LBVH (env MI_PT_BVH=lbvh)    */
+  uint32_t build_rounds; /* PLOC merge rounds                                           */
 } mi_bvh_info;
 
 int mi_pt_bvh_info(mi_pt_handle* h, mi_bvh_info* out);
@@ -255,9 +257,9 @@ int mi_pt_bvh_info(mi_pt_handle* h, mi_bvh_info* out);
  * six section offsets and the total size (float4 units); blob may be NULL to query sizes only. */
 int mi_pt_blob_download(mi_pt_handle* h, uint32_t offsets_f4[7], float* blob, size_t capacity_f4);
 /* nodes: [n_nodes]; sorted_tri: [n_triangles] global triangle id at each sorted position;
- * morton: [n_triangles] 30-bit codes in sorted order.  Any pointer may be NULL. */
+ * morton: [n_triangles] 63-bit codes in sorted order.  Any pointer may be NULL. */
 int mi_pt_bvh_download(mi_pt_handle* h, mi_bvh_node* nodes, uint32_t* sorted_tri,
-                       uint32_t* morton);
+                       uint64_t* morton);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side camera helpers (Cameras.cpp) — exported so tests can pin them against the

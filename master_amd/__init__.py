@@ -89,7 +89,8 @@ class BvhNode(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("n_triangles", C.c_uint32), ("n_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32),
-                ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3), ("build_ms", C.c_double)]
+                ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3), ("build_ms", C.c_double),
+                ("builder", C.c_uint32), ("build_rounds", C.c_uint32)]
 
 
 class CameraFrame(C.Structure):
@@ -467,6 +468,6 @@ class PathTracing:
         info = self.bvh_info()
         nodes = np.zeros(info.n_nodes, NODE_DTYPE)
         sorted_tri = np.zeros(info.n_triangles, np.uint32)
-        morton = np.zeros(info.n_triangles, np.uint32)
+        morton = np.zeros(info.n_triangles, np.uint64)
         _check(lib().mi_pt_bvh_download(self._h, _ptr(nodes), _ptr(sorted_tri), _ptr(morton)))
         return nodes, sorted_tri, morton

@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libmi_pt.so")
 SOURCES = [
     "mi_pt_api.hip",
     "device/pt_kernels.hip",
-    "device/lbvh_build.hip",
+    "device/bvh_build.hip",
     "scene_host.cpp",
     "blend_reader.cpp",
     "exr_io.cpp",

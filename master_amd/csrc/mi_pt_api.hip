@@ -30,7 +30,7 @@ struct mi_pt_handle {
   uint4* qnodes = nullptr;
   mi::SceneView sv{};
   uint32_t* d_sorted_tri = nullptr;
-  uint32_t* d_morton = nullptr;
+  uint64_t* d_morton = nullptr;
   mi_bvh_info info{};
   int kernel_choice = MI_PT_KERNEL_AUTO;
   bool instrumented = false;
@@ -202,12 +202,15 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     rc = upload(&d_idx, s.indices.data(), s.indices.size() * 4); tmpbuf.p[2] = d_idx; if (rc) return rc;
     rc = upload(&d_tm, tri_material.data(), tri_material.size() * 4); tmpbuf.p[3] = d_tm; if (rc) return rc;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_sorted_tri), size_t(nt) * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_morton), size_t(nt) * 4));
-    float build_ms = 0.0f; uint32_t depth = 1;
-    HIP_TRY(mi::build_lbvh(nt, d_pos, d_tan, d_idx, d_tm, reinterpret_cast<mi_bvh_node*>(h->blob + sv.off_nodes), h->blob + sv.off_tris,
-                           h->blob + sv.off_shade, h->d_sorted_tri, h->d_morton, h->info.scene_lo, h->info.scene_hi, &depth, &build_ms,
-                           h->stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_morton), size_t(nt) * 8));
+    float build_ms = 0.0f; uint32_t depth = 1, rounds = 0;
+    const char* bsel = std::getenv("MI_PT_BVH");  // "lbvh" selects the Karras builder (A/B and regression runs)
+    const int builder = (bsel && std::strcmp(bsel, "lbvh") == 0) ? 0 : 1;
+    HIP_TRY(mi::build_bvh(builder, nt, d_pos, d_tan, d_idx, d_tm, reinterpret_cast<mi_bvh_node*>(h->blob + sv.off_nodes), h->blob + sv.off_tris,
+                          h->blob + sv.off_shade, h->d_sorted_tri, h->d_morton, h->info.scene_lo, h->info.scene_hi, &depth, &build_ms,
+                          &rounds, h->stream));
     h->info.n_triangles = nt; h->info.n_nodes = n_nodes; h->info.max_depth = depth; h->info.build_ms = build_ms;
+    h->info.builder = uint32_t(builder); h->info.build_rounds = rounds;
     // quantised node copy on a 65536^3 grid over the scene box (used by the kernels that read the scene from HBM)
     for (int a = 0; a < 3; ++a) {
       // the grid overhangs the scene box by two cells on every side so padded leaf boxes never meet the clamp
@@ -430,13 +433,13 @@ int mi_pt_blob_download(mi_pt_handle* h, uint32_t offsets_f4[7], float* blob, si
   return MI_OK;
 }
 
-int mi_pt_bvh_download(mi_pt_handle* h, mi_bvh_node* nodes, uint32_t* sorted_tri, uint32_t* morton) {
+int mi_pt_bvh_download(mi_pt_handle* h, mi_bvh_node* nodes, uint32_t* sorted_tri, uint64_t* morton) {
   if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_bvh_download: null handle");
   HIP_TRY(hipSetDevice(h->device));
   static_assert(sizeof(mi_bvh_node) == 64, "mi_bvh_node must be 4 float4");
   if (nodes && h->sv.n_nodes) HIP_TRY(hipMemcpy(nodes, h->blob + h->sv.off_nodes, size_t(h->sv.n_nodes) * 64, hipMemcpyDeviceToHost));
   if (sorted_tri) HIP_TRY(hipMemcpy(sorted_tri, h->d_sorted_tri, size_t(h->sv.n_tris) * 4, hipMemcpyDeviceToHost));
-  if (morton) HIP_TRY(hipMemcpy(morton, h->d_morton, size_t(h->sv.n_tris) * 4, hipMemcpyDeviceToHost));
+  if (morton) HIP_TRY(hipMemcpy(morton, h->d_morton, size_t(h->sv.n_tris) * 8, hipMemcpyDeviceToHost));
   return MI_OK;
 }
 

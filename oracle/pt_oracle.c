@@ -44,6 +44,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -168,6 +169,8 @@ typedef struct {
   uint32_t parent;
 } bnode_t;
 
+#define ORC_STACK 256 /* traversal stack entries; the build aborts on a deeper tree */
+
 typedef struct orc_scene {
   mi_scene_desc d; /* deep copy */
   float* positions; float* tangents; uint32_t* indices; uint32_t* mesh_tri_offset;
@@ -176,9 +179,9 @@ typedef struct orc_scene {
   tri_t* tris;            /* [n_triangles] in ORIGINAL order (brute force)        */
   /* light sampler (AreaLights::_updateSampler, AreaLights.cpp:199-214) */
   float* light_weight; float* light_cdf; /* cdf[n_lights+1] */
-  /* LBVH restatement (same algorithm as the device builder; bit-exact comparable) */
-  uint32_t n_nodes; bnode_t* nodes; uint32_t* sorted_tri; uint32_t* morton; tri_t* tris_sorted;
-  float scene_lo[3], scene_hi[3]; uint32_t max_depth;
+  /* BVH restatement (same algorithm as the device builder; bit-exact comparable) */
+  uint32_t n_nodes; bnode_t* nodes; uint32_t* sorted_tri; uint64_t* morton; tri_t* tris_sorted;
+  float scene_lo[3], scene_hi[3]; uint32_t max_depth, builder, build_rounds;
   /* PT params */
   mi_pt_params p;
   int use_bvh;
@@ -194,20 +197,24 @@ static inline v3 s_normal(const surf_t* s) { return s->tangent.c[1]; }
 static inline v3 s_to_world(const surf_t* s, v3 v) { return m3mulv(s->tangent, v); }
 static inline v3 s_to_surface(const surf_t* s, v3 v) { return vmulm3(v, s->tangent); }
 
-/* ------------------------------------------------------------------ LBVH (Karras 2012) */
-static inline uint32_t expand_bits10(uint32_t v) {
-  v = (v * 0x00010001u) & 0xFF0000FFu;
-  v = (v * 0x00000101u) & 0x0F00F00Fu;
-  v = (v * 0x00000011u) & 0xC30C30C3u;
-  v = (v * 0x00000005u) & 0x49249249u;
-  return v;
+/* ------------------------------------------------------------------ BVH2 build (sequential restatement of
+ * master_amd/csrc/device/bvh_build.hip: 63-bit Morton order, then PLOC clustering or the Karras 2012 hierarchy;
+ * the tree is bit-comparable with the device's) */
+static inline uint64_t expand_bits21(uint32_t v) {
+  uint64_t x = v & 0x1FFFFFu;
+  x = (x | (x << 32)) & 0x001F00000000FFFFull;
+  x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+  x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
 }
-static inline uint32_t quant10(float c, float lo, float hi) {
+static inline uint32_t quant21(float c, float lo, float hi) {
   float ext = hi - lo;
   float n = ext > 0.0f ? (c - lo) / ext : 0.0f;
-  float q = n * 1024.0f;
+  float q = n * 2097152.0f;
   if (!(q > 0.0f)) q = 0.0f;
-  if (q > 1023.0f) q = 1023.0f;
+  if (q > 2097151.0f) q = 2097151.0f;
   return (uint32_t)q;
 }
 static inline void tri_bounds(const orc_scene* s, uint32_t t, float lo[3], float hi[3]) {
@@ -226,14 +233,16 @@ static inline void pad_box(float lo[3], float hi[3]) {
     lo[a] = lo[a] - pad; hi[a] = hi[a] + pad;
   }
 }
-typedef struct { uint64_t key; } mkey_t;
+typedef struct { uint64_t code; uint32_t id; } mkey_t;
 static int cmp_key(const void* a, const void* b) {
-  uint64_t x = ((const mkey_t*)a)->key, y = ((const mkey_t*)b)->key;
-  return x < y ? -1 : x > y ? 1 : 0;
+  const mkey_t *x = (const mkey_t*)a, *y = (const mkey_t*)b;
+  if (x->code != y->code) return x->code < y->code ? -1 : 1;
+  return x->id < y->id ? -1 : x->id > y->id ? 1 : 0;
 }
-static inline int delta_fn(const uint64_t* keys, int n, int i, int j) {
+static inline int delta_fn(const mkey_t* keys, int n, int i, int j) { /* common prefix of the 96-bit key (code, id) */
   if (j < 0 || j >= n) return -1;
-  return __builtin_clzll(keys[i] ^ keys[j]);
+  uint64_t x = keys[i].code ^ keys[j].code;
+  return x ? __builtin_clzll(x) : 64 + __builtin_clz(keys[i].id ^ keys[j].id);
 }
 static void node_child_box(const orc_scene* s, int32_t link, float lo[3], float hi[3]) {
   if (link < 0) {
@@ -259,8 +268,105 @@ static uint32_t depth_of(const orc_scene* s, int32_t link) {
   uint32_t a = depth_of(s, s->nodes[link].link[0]), b = depth_of(s, s->nodes[link].link[1]);
   return 1 + (a > b ? a : b);
 }
-static void build_lbvh(orc_scene* s) {
+/* PLOC (Meister & Bittner 2018) as the device runs it: clusters in Morton order, every cluster picks the partner
+ * within 16 places minimising (union area, pair hash, min index, max index), mutual pairs merge, survivors keep
+ * their order.  Nodes are numbered downwards so that the root is node 0. */
+#define PLOC_RADIUS 16
+typedef struct { float lo[3], hi[3]; int32_t link; } cluster_t;
+static inline float union_area(const cluster_t* a, const cluster_t* b) {
+  float dx = fmaxf(a->hi[0], b->hi[0]) - fminf(a->lo[0], b->lo[0]);
+  float dy = fmaxf(a->hi[1], b->hi[1]) - fminf(a->lo[1], b->lo[1]);
+  float dz = fmaxf(a->hi[2], b->hi[2]) - fminf(a->lo[2], b->lo[2]);
+  return fmaf(dx, dy, fmaf(dy, dz, dz * dx));
+}
+static inline uint32_t pair_hash(uint32_t a, uint32_t b) {
+  uint32_t h = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u + 0x165667B1u);
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+static int build_ploc(orc_scene* s, int n, uint32_t* rounds_out) {
+  cluster_t* a = (cluster_t*)malloc(sizeof(cluster_t) * (size_t)n);
+  cluster_t* b = (cluster_t*)malloc(sizeof(cluster_t) * (size_t)n);
+  int* nn = (int*)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    tri_bounds(s, s->sorted_tri[i], a[i].lo, a[i].hi);
+    pad_box(a[i].lo, a[i].hi);
+    a[i].link = ~i;
+  }
+  int cur = n; uint32_t next = (uint32_t)(n - 1), rounds = 0;
+  while (cur > 1) {
+    for (int i = 0; i < cur; ++i) {
+      int best = -1; float best_area = 0.0f;
+      int j0 = i - PLOC_RADIUS < 0 ? 0 : i - PLOC_RADIUS, j1 = i + PLOC_RADIUS > cur - 1 ? cur - 1 : i + PLOC_RADIUS;
+      for (int j = j0; j <= j1; ++j) {
+        if (j == i) continue;
+        float area = union_area(&a[i], &a[j]);
+        int take;
+        if (best < 0) take = 1;
+        else if (area != best_area) take = area < best_area;
+        else {
+          uint32_t a0 = (uint32_t)(i < j ? i : j), a1 = (uint32_t)(i < j ? j : i);
+          uint32_t b0 = (uint32_t)(i < best ? i : best), b1 = (uint32_t)(i < best ? best : i);
+          uint32_t ha = pair_hash(a0, a1), hb = pair_hash(b0, b1);
+          take = ha != hb ? ha < hb : (a0 != b0 ? a0 < b0 : a1 < b1);
+        }
+        if (take) { best = j; best_area = area; }
+      }
+      nn[i] = best;
+    }
+    uint32_t leaders = 0; int out = 0;
+    for (int i = 0; i < cur; ++i) {
+      int j = nn[i];
+      int mutual = nn[j] == i;
+      if (mutual && i > j) continue; /* absorbed by its partner */
+      if (!mutual) { b[out++] = a[i]; continue; }
+      uint32_t node = next - 1u - leaders++;
+      bnode_t* nd = &s->nodes[node];
+      for (int k = 0; k < 3; ++k) {
+        nd->lo[0][k] = a[i].lo[k]; nd->hi[0][k] = a[i].hi[k];
+        nd->lo[1][k] = a[j].lo[k]; nd->hi[1][k] = a[j].hi[k];
+        b[out].lo[k] = fminf(a[i].lo[k], a[j].lo[k]); b[out].hi[k] = fmaxf(a[i].hi[k], a[j].hi[k]);
+      }
+      nd->link[0] = a[i].link; nd->link[1] = a[j].link; nd->parent = UINT32_MAX;
+      if (a[i].link >= 0) s->nodes[a[i].link].parent = node;
+      if (a[j].link >= 0) s->nodes[a[j].link].parent = node;
+      b[out++].link = (int32_t)node;
+    }
+    if (leaders == 0) { free(a); free(b); free(nn); return -1; }
+    cur = out; next -= leaders; ++rounds;
+    cluster_t* t = a; a = b; b = t;
+  }
+  free(a); free(b); free(nn);
+  *rounds_out = rounds;
+  if (next != 0) return -1;
+  /* depth-first (pre-order) renumbering: subtrees become contiguous, the first child follows its parent */
+  uint32_t nn_nodes = (uint32_t)(n - 1);
+  bnode_t* src = (bnode_t*)malloc(sizeof(bnode_t) * nn_nodes);
+  uint32_t* new_index = (uint32_t*)malloc(sizeof(uint32_t) * nn_nodes);
+  int32_t* stack = (int32_t*)malloc(sizeof(int32_t) * (nn_nodes + 1));
+  memcpy(src, s->nodes, sizeof(bnode_t) * nn_nodes);
+  uint32_t counter = 0; int sp = 0; stack[sp++] = 0;
+  while (sp) {
+    int32_t x = stack[--sp];
+    new_index[x] = counter++;
+    if (src[x].link[1] >= 0) stack[sp++] = src[x].link[1];
+    if (src[x].link[0] >= 0) stack[sp++] = src[x].link[0];
+  }
+  for (uint32_t x = 0; x < nn_nodes; ++x) {
+    bnode_t nd = src[x];
+    for (int c = 0; c < 2; ++c) if (nd.link[c] >= 0) nd.link[c] = (int32_t)new_index[nd.link[c]];
+    if (nd.parent != UINT32_MAX) nd.parent = new_index[nd.parent];
+    s->nodes[new_index[x]] = nd;
+  }
+  free(src); free(new_index); free(stack);
+  return 0;
+}
+
+static void build_bvh(orc_scene* s) {
   int n = (int)s->d.n_triangles;
+  const char* bsel = getenv("MI_PT_BVH"); /* same switch as the product: "lbvh" = Karras hierarchy */
+  s->builder = (bsel && strcmp(bsel, "lbvh") == 0) ? 0 : 1;
+  s->build_rounds = 0;
   for (int a = 0; a < 3; ++a) { s->scene_lo[a] = INFINITY; s->scene_hi[a] = -INFINITY; }
   for (int t = 0; t < n; ++t) {
     float lo[3], hi[3]; tri_bounds(s, t, lo, hi);
@@ -273,38 +379,39 @@ static void build_lbvh(orc_scene* s) {
   for (int t = 0; t < n; ++t) {
     float lo[3], hi[3]; tri_bounds(s, t, lo, hi);
     uint32_t q[3];
-    for (int a = 0; a < 3; ++a) q[a] = quant10((lo[a] + hi[a]) * 0.5f, s->scene_lo[a], s->scene_hi[a]);
-    uint32_t code = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
-    keys[t].key = ((uint64_t)code << 32) | (uint32_t)t;
+    for (int a = 0; a < 3; ++a) q[a] = quant21((lo[a] + hi[a]) * 0.5f, s->scene_lo[a], s->scene_hi[a]);
+    keys[t].code = (expand_bits21(q[0]) << 2) | (expand_bits21(q[1]) << 1) | expand_bits21(q[2]);
+    keys[t].id = (uint32_t)t;
   }
   qsort(keys, (size_t)n, sizeof(mkey_t), cmp_key);
   s->sorted_tri = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
-  s->morton = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+  s->morton = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
   s->tris_sorted = (tri_t*)malloc(sizeof(tri_t) * (size_t)n);
-  uint64_t* k64 = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
   for (int i = 0; i < n; ++i) {
-    k64[i] = keys[i].key;
-    s->sorted_tri[i] = (uint32_t)(keys[i].key & 0xFFFFFFFFu);
-    s->morton[i] = (uint32_t)(keys[i].key >> 32);
+    s->sorted_tri[i] = keys[i].id;
+    s->morton[i] = keys[i].code;
     s->tris_sorted[i] = s->tris[s->sorted_tri[i]];
   }
   s->n_nodes = n > 1 ? (uint32_t)(n - 1) : 0;
   s->nodes = (bnode_t*)calloc(s->n_nodes ? s->n_nodes : 1, sizeof(bnode_t));
-  for (int i = 0; i < (int)s->n_nodes; ++i) {
-    int d = (delta_fn(k64, n, i, i + 1) - delta_fn(k64, n, i, i - 1)) >= 0 ? 1 : -1;
-    int dmin = delta_fn(k64, n, i, i - d);
+  if (s->n_nodes && s->builder == 1) {
+    if (build_ploc(s, n, &s->build_rounds) != 0) { fprintf(stderr, "oracle: PLOC build stalled\n"); abort(); }
+  }
+  for (int i = 0; s->builder == 0 && i < (int)s->n_nodes; ++i) {
+    int d = (delta_fn(keys, n, i, i + 1) - delta_fn(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta_fn(keys, n, i, i - d);
     int lmax = 2;
-    while (delta_fn(k64, n, i, i + lmax * d) > dmin) lmax *= 2;
+    while (delta_fn(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
     int l = 0;
     for (int t = lmax / 2; t >= 1; t /= 2)
-      if (delta_fn(k64, n, i, i + (l + t) * d) > dmin) l += t;
+      if (delta_fn(keys, n, i, i + (l + t) * d) > dmin) l += t;
     int j = i + l * d;
-    int dnode = delta_fn(k64, n, i, j);
+    int dnode = delta_fn(keys, n, i, j);
     int sp = 0;
     int t = l;
     do {
       t = (t + 1) / 2;
-      if (delta_fn(k64, n, i, i + (sp + t) * d) > dnode) sp += t;
+      if (delta_fn(keys, n, i, i + (sp + t) * d) > dnode) sp += t;
     } while (t > 1);
     int gamma = i + sp * d + (d < 0 ? d : 0);
     int lo_i = i < j ? i : j, hi_i = i < j ? j : i;
@@ -314,9 +421,13 @@ static void build_lbvh(orc_scene* s) {
     if (left >= 0) s->nodes[left].parent = (uint32_t)i;
     if (right >= 0) s->nodes[right].parent = (uint32_t)i;
   }
-  if (s->n_nodes) { s->nodes[0].parent = UINT32_MAX; refit(s, 0); s->max_depth = depth_of(s, 0); }
-  else s->max_depth = 1;
-  free(keys); free(k64);
+  if (s->n_nodes) {
+    s->nodes[0].parent = UINT32_MAX;
+    if (s->builder == 0) refit(s, 0);
+    s->max_depth = depth_of(s, 0);
+    if (s->max_depth > ORC_STACK) { fprintf(stderr, "oracle: BVH depth %u exceeds the traversal stack\n", s->max_depth); abort(); }
+  } else s->max_depth = 1;
+  free(keys);
 }
 
 /* ------------------------------------------------------------------ ray / triangle (Embree 2 MT) */
@@ -368,7 +479,7 @@ static void traverse(const orc_scene* s, v3 org, v3 dir, uint32_t ray_mask, hit_
     return;
   }
   v3 inv = V(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-  int32_t stack[128]; int sp = 0;
+  int32_t stack[ORC_STACK]; int sp = 0;
   int32_t node = 0;
   for (;;) {
     if (node >= 0) {
@@ -774,7 +885,7 @@ ORC_API orc_scene* orc_create(const mi_scene_desc* d, const mi_pt_params* p, int
     s->light_weight[i] = light_area(&s->lights[i]) * l1norm(ld3(s->lights[i].exitance)) * total_inv;
     s->light_cdf[i + 1] = s->light_cdf[i] + s->light_weight[i];
   }
-  build_lbvh(s);
+  build_bvh(s);
   return s;
 }
 ORC_API void orc_destroy(orc_scene* s) {
@@ -790,15 +901,16 @@ ORC_API void orc_bvh_info(const orc_scene* s, mi_bvh_info* out) {
   memset(out, 0, sizeof *out);
   out->n_triangles = s->d.n_triangles; out->n_nodes = s->n_nodes; out->max_depth = s->max_depth;
   memcpy(out->scene_lo, s->scene_lo, 12); memcpy(out->scene_hi, s->scene_hi, 12);
+  out->builder = s->builder; out->build_rounds = s->build_rounds;
 }
-ORC_API void orc_bvh_download(const orc_scene* s, mi_bvh_node* nodes, uint32_t* sorted_tri, uint32_t* morton) {
+ORC_API void orc_bvh_download(const orc_scene* s, mi_bvh_node* nodes, uint32_t* sorted_tri, uint64_t* morton) {
   if (nodes) for (uint32_t i = 0; i < s->n_nodes; ++i) {
     const bnode_t* n = &s->nodes[i]; mi_bvh_node* o = &nodes[i];
     memcpy(o->lo0, n->lo[0], 12); memcpy(o->hi0, n->hi[0], 12); memcpy(o->lo1, n->lo[1], 12); memcpy(o->hi1, n->hi[1], 12);
     o->link0 = n->link[0]; o->link1 = n->link[1]; o->parent = n->parent; o->reserved = 0;
   }
   if (sorted_tri) memcpy(sorted_tri, s->sorted_tri, sizeof(uint32_t) * s->d.n_triangles);
-  if (morton) memcpy(morton, s->morton, sizeof(uint32_t) * s->d.n_triangles);
+  if (morton) memcpy(morton, s->morton, sizeof(uint64_t) * s->d.n_triangles);
 }
 
 static surf_t surf_from_abi(const mi_surface_point* p) {

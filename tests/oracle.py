@@ -126,7 +126,7 @@ class Oracle:
         info = self.bvh_info()
         nodes = np.zeros(info.n_nodes, ma.NODE_DTYPE)
         sorted_tri = np.zeros(info.n_triangles, np.uint32)
-        morton = np.zeros(info.n_triangles, np.uint32)
+        morton = np.zeros(info.n_triangles, np.uint64)
         lib().orc_bvh_download(self._h, _ptr(nodes), _ptr(sorted_tri), _ptr(morton))
         return nodes, sorted_tri, morton
 

@@ -31,7 +31,15 @@ def grid_paths(w, h, spp):
     return np.tile(xy, (spp, 1)), np.repeat(np.arange(spp, dtype=np.uint64), w * h)
 
 
-SCENES = ["CornellBoxDiffuse", "CornellBoxSpecular", "TestCaseFurnace", "TestCase0", "DoubleLight", "soup300", "soup20000", "single"]
+SCENES = ["CornellBoxDiffuse", "CornellBoxSpecular", "TestCaseFurnace", "TestCase0", "DoubleLight", "soup300", "soup20000", "single",
+          "MirrorBalls", "MetalRings", "LivingRoomLit"]  # the last three: real models with far-away lights / mixed triangle sizes
+
+
+@pytest.fixture(params=["ploc", "lbvh"])
+def builder(request, monkeypatch):
+    """Both hierarchy builders; the product and the oracle read the same MI_PT_BVH switch at scene creation."""
+    monkeypatch.setenv("MI_PT_BVH", request.param)
+    return request.param
 
 
 def get_scene(name):
@@ -48,11 +56,12 @@ def get_scene(name):
 
 
 @pytest.mark.parametrize("name", SCENES)
-def test_lbvh_bit_exact(name):
+def test_bvh_bit_exact(builder, name):
     s = get_scene(name)
     pt, orc = ma.PathTracing(s), oracle.Oracle(s)
     gi, oi = pt.bvh_info(), orc.bvh_info()
-    assert (gi.n_nodes, gi.max_depth) == (oi.n_nodes, oi.max_depth)
+    assert (gi.n_nodes, gi.max_depth, gi.builder, gi.build_rounds) == (oi.n_nodes, oi.max_depth, oi.builder, oi.build_rounds)
+    assert gi.builder == (1 if builder == "ploc" else 0)
     assert list(gi.scene_lo) == list(oi.scene_lo) and list(gi.scene_hi) == list(oi.scene_hi)
     gn, gs, gm = pt.bvh(); on, os_, om = orc.bvh()
     assert np.array_equal(gm, om) and np.array_equal(gs, os_)
@@ -61,7 +70,7 @@ def test_lbvh_bit_exact(name):
 
 
 @pytest.mark.parametrize("name", SCENES)
-def test_intersect_and_occluded_bit_exact(name):
+def test_intersect_and_occluded_bit_exact(builder, name):
     s = get_scene(name)
     pt, orc = ma.PathTracing(s), oracle.Oracle(s)
     o, d = rays(s, 100000, 1)
@@ -71,8 +80,9 @@ def test_intersect_and_occluded_bit_exact(name):
     assert np.array_equal(pt.occluded(o, tg), orc.occluded(o, tg))
     # traversal == brute force (oracle without its BVH): exact t, exact primitive
     orc.set_use_bvh(False)
-    _, bt, bp = orc.intersect(o[:20000], d[:20000])
-    assert np.array_equal(gp[:20000], bp) and np.array_equal(gt[:20000], bt)
+    nb = 20000 if s.n_triangles <= 20000 else 3000
+    _, bt, bp = orc.intersect(o[:nb], d[:nb])
+    assert np.array_equal(gp[:nb], bp) and np.array_equal(gt[:nb], bt)
 
 
 def test_intersect_edge_cases(cornell):

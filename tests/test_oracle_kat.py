@@ -46,9 +46,32 @@ def test_cornell_lbvh_and_paths_regression_pins(cornell):
         assert int(cnt[:, 0].sum()) == c["basic"] and int(cnt[:, 1].sum()) == c["shadow"]
 
 
-def test_lbvh_is_a_valid_hierarchy():
-    s = sb.random_soup(3000, seed=3)
+def _flat_grid(nu, nv):
+    """nu x nv identical quads in a plane: every neighbour pair has the same union area (PLOC tie-breaking)."""
+    b = sb.FastBuilder()
+    b.add_camera((0, -3, 2), (0, 1, -0.5))
+    m = b.add_material(sb.material(ma.BSDF_DIFFUSE, diffuse=(0.5, 0.5, 0.5)))
+    tris, nrm = sb.grid(nu, nv, lambda u, v: (np.stack([u * 4 - 2, v * 4 - 2, 0 * u], -1), np.stack([0 * u, 0 * u, 0 * u + 1], -1)))
+    b.add_tris(tris, nrm, m)
+    b.add_light((0, 0, 3), (0, 0, -1), (0, 1, 0), (1, 1), (5, 5, 5))
+    return b.build()
+
+
+@pytest.fixture(params=["ploc", "lbvh"])
+def builder(request, monkeypatch):
+    """Both hierarchy builders (the product and the oracle read the same MI_PT_BVH switch)."""
+    monkeypatch.setenv("MI_PT_BVH", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("kind", ["soup", "grid"])
+def test_bvh_is_a_valid_hierarchy(builder, kind):
+    s = sb.random_soup(3000, seed=3) if kind == "soup" else _flat_grid(48, 48)
     o = oracle.Oracle(s)
+    info = o.bvh_info()
+    assert info.builder == (1 if builder == "ploc" else 0)
+    if builder == "ploc":  # a constant fraction of the clusters merges per round, also when all areas tie
+        assert 0 < info.build_rounds <= 8 * int(np.ceil(np.log2(s.n_triangles)))
     nodes, order, morton = o.bvh()
     n = s.n_triangles
     assert sorted(order.tolist()) == list(range(n)) and np.all(np.diff(morton.astype(np.int64)) >= 0)
@@ -78,8 +101,8 @@ def _rays(scene, n, seed):
     return o, d.astype(np.float32)
 
 
-@pytest.mark.parametrize("scene_name", ["CornellBoxDiffuse", "CornellBoxSpecular", "soup"])
-def test_bvh_traversal_equals_brute_force(scene_name):
+@pytest.mark.parametrize("scene_name", ["CornellBoxDiffuse", "CornellBoxSpecular", "MirrorBalls", "soup"])
+def test_bvh_traversal_equals_brute_force(builder, scene_name):
     s = sb.random_soup(2000, seed=5) if scene_name == "soup" else load_scene(scene_name)
     o = oracle.Oracle(s, use_bvh=True)
     org, d = _rays(s, 20000, 1)

@@ -169,6 +169,10 @@ typedef struct {
   uint32_t parent;
 } bnode_t;
 
+#ifndef ORC_COUNT_NODE /* hooks for tests/lab (tree-quality experiments); empty in the oracle proper */
+#define ORC_COUNT_NODE(closest)
+#define ORC_COUNT_TRI(closest)
+#endif
 #define ORC_STACK 256 /* traversal stack entries; the build aborts on a deeper tree */
 
 typedef struct orc_scene {
@@ -478,6 +482,9 @@ static void traverse(const orc_scene* s, v3 org, v3 dir, uint32_t ray_mask, hit_
       if (tri_test(&s->tris[i], org, dir, ray_mask, 0.0f, h, closest) && !closest) return;
     return;
   }
+  /* a NaN direction (TransmissionBSDF past the critical angle, BSDF.cpp:467-504) can hit nothing: every dot product in
+   * tri_test is NaN.  Leave before the slab test, whose NaN-ignoring min/max would open every box of the tree. */
+  if (dir.x != dir.x || dir.y != dir.y || dir.z != dir.z) return;
   v3 inv = V(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
   int32_t stack[ORC_STACK]; int sp = 0;
   int32_t node = 0;
@@ -485,6 +492,7 @@ static void traverse(const orc_scene* s, v3 org, v3 dir, uint32_t ray_mask, hit_
     if (node >= 0) {
       const bnode_t* nd = &s->nodes[node];
       float tn0, tn1;
+      ORC_COUNT_NODE(closest);
       int h0 = box_test(nd->lo[0], nd->hi[0], org, inv, h->t, &tn0);
       int h1 = box_test(nd->lo[1], nd->hi[1], org, inv, h->t, &tn1);
       if (h0 && h1) {
@@ -495,6 +503,7 @@ static void traverse(const orc_scene* s, v3 org, v3 dir, uint32_t ray_mask, hit_
       } else if (h0) { node = nd->link[0]; continue; }
       else if (h1) { node = nd->link[1]; continue; }
     } else {
+      ORC_COUNT_TRI(closest);
       if (tri_test(&s->tris_sorted[~node], org, dir, ray_mask, 0.0f, h, closest) && !closest) return;
     }
     if (sp == 0) return;

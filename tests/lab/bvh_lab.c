@@ -1,0 +1,131 @@
+/* bvh_lab.c — tree-quality experiments on the CPU: builds the oracle's scene, optionally replaces / post-processes
+ * its BVH, and counts node visits and triangle tests over real path segments (orc_trace_paths).
+ * Test infrastructure only (includes the oracle source).  Build: see tests/lab/run_lab.py. */
+#include <stdint.h>
+static __thread uint64_t g_cnt[4]; /* nodes closest, tris closest, nodes shadow, tris shadow */
+#define ORC_COUNT_NODE(closest) (g_cnt[(closest) ? 0 : 2]++)
+#define ORC_COUNT_TRI(closest) (g_cnt[(closest) ? 1 : 3]++)
+#include "../../oracle/pt_oracle.c"
+
+ORC_API void lab_counters(uint64_t out[4], int reset) { for (int i = 0; i < 4; ++i) { out[i] = g_cnt[i]; if (reset) g_cnt[i] = 0; } }
+
+/* ---- helpers over the node array ---- */
+static float box_area(const float lo[3], const float hi[3]) {
+  float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+ORC_API double lab_sah(const orc_scene* s) {
+  if (!s->n_nodes) return 0;
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) { lo[a] = fminf(s->nodes[0].lo[0][a], s->nodes[0].lo[1][a]); hi[a] = fmaxf(s->nodes[0].hi[0][a], s->nodes[0].hi[1][a]); }
+  double root = box_area(lo, hi), sum = root;
+  for (uint32_t i = 0; i < s->n_nodes; ++i) for (int c = 0; c < 2; ++c) sum += box_area(s->nodes[i].lo[c], s->nodes[i].hi[c]);
+  return sum / root;
+}
+
+/* ---- top-down full-sweep SAH over the Morton-sorted leaves (reference quality) ---- */
+typedef struct { float lo[3], hi[3], c[3]; int32_t leaf; } prim_t;
+static int g_axis;
+static int cmp_prim(const void* a, const void* b) {
+  float x = ((const prim_t*)a)->c[g_axis], y = ((const prim_t*)b)->c[g_axis];
+  return x < y ? -1 : x > y ? 1 : 0;
+}
+static uint32_t g_next;
+static int32_t sah_build(orc_scene* s, prim_t* p, int n, float* tmp, float out_lo[3], float out_hi[3]) {
+  for (int a = 0; a < 3; ++a) { out_lo[a] = INFINITY; out_hi[a] = -INFINITY; }
+  for (int i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { out_lo[a] = fminf(out_lo[a], p[i].lo[a]); out_hi[a] = fmaxf(out_hi[a], p[i].hi[a]); }
+  if (n == 1) return p[0].leaf;
+  int best_axis = 0, best_k = n / 2; float best = INFINITY;
+  for (int ax = 0; ax < 3; ++ax) {
+    g_axis = ax; qsort(p, (size_t)n, sizeof(prim_t), cmp_prim);
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = n - 1; i > 0; --i) { for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[i].lo[a]); hi[a] = fmaxf(hi[a], p[i].hi[a]); } tmp[i] = box_area(lo, hi) * (float)(n - i); }
+    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (int i = 0; i < n - 1; ++i) {
+      for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[i].lo[a]); hi[a] = fmaxf(hi[a], p[i].hi[a]); }
+      float c = box_area(lo, hi) * (float)(i + 1) + tmp[i + 1];
+      if (c < best) { best = c; best_axis = ax; best_k = i + 1; }
+    }
+  }
+  g_axis = best_axis; qsort(p, (size_t)n, sizeof(prim_t), cmp_prim);
+  uint32_t me = g_next++;
+  float l0[3], h0[3], l1[3], h1[3];
+  int32_t a = sah_build(s, p, best_k, tmp, l0, h0);
+  int32_t b = sah_build(s, p + best_k, n - best_k, tmp, l1, h1);
+  bnode_t* nd = &s->nodes[me];
+  for (int k = 0; k < 3; ++k) { nd->lo[0][k] = l0[k]; nd->hi[0][k] = h0[k]; nd->lo[1][k] = l1[k]; nd->hi[1][k] = h1[k]; }
+  nd->link[0] = a; nd->link[1] = b;
+  if (a >= 0) s->nodes[a].parent = me;
+  if (b >= 0) s->nodes[b].parent = me;
+  return (int32_t)me;
+}
+ORC_API void lab_build_sah(orc_scene* s) {
+  int n = (int)s->d.n_triangles;
+  if (n < 2) return;
+  prim_t* p = (prim_t*)malloc(sizeof(prim_t) * (size_t)n);
+  float* tmp = (float*)malloc(sizeof(float) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    tri_bounds(s, s->sorted_tri[i], p[i].lo, p[i].hi); pad_box(p[i].lo, p[i].hi);
+    for (int a = 0; a < 3; ++a) p[i].c[a] = 0.5f * (p[i].lo[a] + p[i].hi[a]);
+    p[i].leaf = ~i;
+  }
+  g_next = 0; float lo[3], hi[3];
+  sah_build(s, p, n, tmp, lo, hi);
+  s->nodes[0].parent = UINT32_MAX;
+  s->max_depth = depth_of(s, 0);
+  free(p); free(tmp);
+}
+
+/* ---- tree rotations (Kensler 2008): swap a child with a grandchild under the other child when it lowers the
+ * surface area of that other child; bottom-up sweeps until no change or `passes` ---- */
+static void child_box(const orc_scene* s, int32_t node, int c, float lo[3], float hi[3]) {
+  for (int a = 0; a < 3; ++a) { lo[a] = s->nodes[node].lo[c][a]; hi[a] = s->nodes[node].hi[c][a]; }
+}
+static float union_area2(const float alo[3], const float ahi[3], const float blo[3], const float bhi[3]) {
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) { lo[a] = fminf(alo[a], blo[a]); hi[a] = fmaxf(ahi[a], bhi[a]); }
+  return box_area(lo, hi);
+}
+static int rotate_node(orc_scene* s, int32_t x) {
+  bnode_t* nd = &s->nodes[x];
+  int changed = 0;
+  for (int c = 0; c < 2; ++c) {          /* child c stays a child; the other child o must be internal */
+    int o = 1 - c; int32_t y = nd->link[o];
+    if (y < 0) continue;
+    bnode_t* yn = &s->nodes[y];
+    float clo[3], chi[3]; child_box(s, x, c, clo, chi);
+    float cur = box_area(nd->lo[o], nd->hi[o]);
+    /* option g: swap child c of x with grandchild g of y -> y becomes (c, other grandchild) */
+    int bestg = -1; float best = cur;
+    for (int g = 0; g < 2; ++g) {
+      float a = union_area2(clo, chi, yn->lo[1 - g], yn->hi[1 - g]);
+      if (a < best) { best = a; bestg = g; }
+    }
+    if (bestg < 0) continue;
+    int g = bestg;
+    int32_t cl = nd->link[c], gl = yn->link[g];
+    float glo[3], ghi[3]; child_box(s, y, g, glo, ghi);
+    /* x.child[c] <- grandchild g ; y.child[g] <- old child c */
+    for (int a = 0; a < 3; ++a) { nd->lo[c][a] = glo[a]; nd->hi[c][a] = ghi[a]; yn->lo[g][a] = clo[a]; yn->hi[g][a] = chi[a]; }
+    nd->link[c] = gl; yn->link[g] = cl;
+    if (gl >= 0) s->nodes[gl].parent = (uint32_t)x;
+    if (cl >= 0) s->nodes[cl].parent = (uint32_t)y;
+    for (int a = 0; a < 3; ++a) { nd->lo[o][a] = fminf(yn->lo[0][a], yn->lo[1][a]); nd->hi[o][a] = fmaxf(yn->hi[0][a], yn->hi[1][a]); }
+    changed = 1;
+  }
+  return changed;
+}
+static int rotate_post(orc_scene* s, int32_t x) {
+  int ch = 0;
+  for (int c = 0; c < 2; ++c) if (s->nodes[x].link[c] >= 0) ch += rotate_post(s, s->nodes[x].link[c]);
+  /* children may have changed boxes: refresh this node's child boxes */
+  for (int c = 0; c < 2; ++c) { int32_t l = s->nodes[x].link[c]; if (l >= 0) for (int a = 0; a < 3; ++a) {
+    s->nodes[x].lo[c][a] = fminf(s->nodes[l].lo[0][a], s->nodes[l].lo[1][a]); s->nodes[x].hi[c][a] = fmaxf(s->nodes[l].hi[0][a], s->nodes[l].hi[1][a]); } }
+  return ch + rotate_node(s, x);
+}
+ORC_API int lab_rotate(orc_scene* s, int passes) {
+  int total = 0;
+  for (int p = 0; p < passes; ++p) { int c = rotate_post(s, 0); total += c; if (!c) break; }
+  s->max_depth = depth_of(s, 0);
+  return total;
+}

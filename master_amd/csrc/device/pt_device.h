@@ -91,8 +91,12 @@ MI_DEV bool box_test(f3 lo, f3 hi, const RayBox& rb, float tmax, float& tnear) {
 // lanes hit consecutive banks); deeper levels — rare, traversal keeps few far children pending — go to a
 // private (scratch) array, so LDS per workgroup stays at `cap` KB however deep the LBVH is.
 constexpr uint32_t kStackSpill = 64;
+// The LDS part is addressed through an address-space-3 pointer: with a generic pointer the compiler cannot prove the
+// target is LDS next to the private spill array and falls back to FLAT loads/stores with 64-bit address arithmetic
+// on the pop -> next-node critical path; this way push/pop are ds_write_b32 / ds_read_b32.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct TravStack {
-  uint32_t* lds;
+  lds_u32* lds;
   uint32_t cap;
   uint32_t spill[kStackSpill];
   MI_DEV void push(int sp, uint32_t v) {

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) vo
     sb = smem;
   }
   TravStack stack;
-  stack.lds = reinterpret_cast<uint32_t*>(smem + blob_f4) + tid;
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + blob_f4) + tid);
   stack.cap = p.stack_entries;
   char* acc_base = reinterpret_cast<char*>(smem + blob_f4) + size_t(p.stack_entries) * kBlock * 4 + size_t(wave) * kAccBytesPerWave;
   double* acc_r = reinterpret_cast<double*>(acc_base);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t sta
                                                      float* __restrict__ out_t, uint32_t* __restrict__ out_prim) {
   extern __shared__ float4 smem[];
   TravStack stack;
-  stack.lds = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
   stack.cap = stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
                                                     const mi_surface_point* __restrict__ b, float* __restrict__ out) {
   extern __shared__ float4 smem[];
   TravStack stack;
-  stack.lds = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
   stack.cap = stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;

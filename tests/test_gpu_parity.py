@@ -6,6 +6,8 @@ because oracle and device state the same arithmetic contract — bit-exact for t
 the diffuse / mirror / dielectric paths too.  Where a library pow() is involved (Phong, beta not
 in {1, 2}) the tolerance is written in the test.  Full-size runs use size-independent properties
 (sample counts, additivity over sample ranges, determinism, furnace value)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -276,6 +278,33 @@ def test_phong_scene_within_stated_tolerance():
     assert close.mean() > 0.995, close.mean()
     img = pt.render_rgbn(64, 64, spp=64, seed=1)[..., :3] / 64; ref = orc.render_rgbn(64, 64, spp=64, seed=1)[..., :3] / 64
     assert abs(img.mean() - ref.mean()) / ref.mean() < 2e-3
+
+
+def _corpus():
+    """Every .miscene fixture below 1 MB: the reference's own models (tools/make_scenes.py) — sun lights, glass of several
+    IORs, mirrors, Phong, meshes from 4 to 5 332 triangles."""
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scenes")
+    return sorted(f[:-8] for f in os.listdir(d) if f.endswith(".miscene") and os.path.getsize(os.path.join(d, f)) < 1000000)
+
+
+@pytest.mark.parametrize("name", _corpus())
+def test_reference_corpus_parity(name):
+    """Tree, ray counts and per-path radiance against the oracle on every model of the reference that fits a fixture.
+    Bit-exact where no library pow() is involved; Phong scenes (material type 2) within the stated 5e-5."""
+    s = load_scene(name)
+    pt, orc = ma.PathTracing(s), oracle.Oracle(s)
+    gn, gs, gm = pt.bvh(); on, os_, om = orc.bvh()
+    assert np.array_equal(gm, om) and np.array_equal(gs, os_) and gn.tobytes() == on.tobytes()
+    rng = np.random.default_rng(17); n = 6000
+    xy = np.stack([rng.integers(0, 96, n), rng.integers(0, 54, n)], 1).astype(np.uint32); si = rng.integers(0, 32, n).astype(np.uint64)
+    g, gc = pt.trace_paths(96, 54, xy, si, seed=11); r, rc = orc.trace_paths(96, 54, xy, si, seed=11)
+    if any(m.type == ma.BSDF_PHONG for m in s.materials):
+        assert (gc == rc).all(1).mean() > 0.995
+        assert np.isclose(g, r, rtol=5e-5, atol=1e-6, equal_nan=True).all(1).mean() > 0.995
+    else:
+        assert np.array_equal(gc, rc)
+        same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
+        assert same.all(), "mismatching paths: %s" % np.nonzero(~same.all(1))[0][:10]
 
 
 def test_4k_frame_and_window_against_oracle(cornell):

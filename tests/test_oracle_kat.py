@@ -259,3 +259,19 @@ def test_rms_abs_errors_definition():
     for fn in (ma.rms_abs_errors, oracle.rms_abs_errors):
         rms, ab = fn(rgbn, ref)
         assert rms == pytest.approx(math.sqrt((d ** 2).sum() / d.size), rel=1e-5) and ab == pytest.approx(d.sum() / d.size, rel=1e-5)
+
+
+def test_oracle_runs_the_whole_reference_corpus():
+    """Every model fixture: finite radiance, at least the camera segment per path, no shadow rays where every light is a
+    sun (PT.cpp:105-107 returns before Scene::occluded when the emitter's BSDF throughput is zero)."""
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scenes")
+    names = sorted(f[:-8] for f in os.listdir(d) if f.endswith(".miscene") and os.path.getsize(os.path.join(d, f)) < 1000000)
+    assert len(names) >= 55
+    rng = np.random.default_rng(1); k = 800
+    xy = np.stack([rng.integers(0, 64, k), rng.integers(0, 36, k)], 1).astype(np.uint32); si = rng.integers(0, 16, k).astype(np.uint64)
+    for n in names:
+        s = load_scene(n)
+        rad, cnt = oracle.Oracle(s).trace_paths(64, 36, xy, si, seed=5)
+        assert np.isfinite(rad).all() and (cnt[:, 0] >= 1).all(), n
+        if all(l.diffuse == 0 for l in s.lights):
+            assert cnt[:, 1].sum() == 0, n

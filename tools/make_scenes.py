@@ -13,7 +13,14 @@ import master_amd as ma  # noqa: E402
 
 SCENES = ["CornellBoxDiffuse", "CornellBoxPhong", "CornellBoxSpecular", "TestCaseFurnace", "TestCase0", "TestCase1", "TestCase2",
           "TestCase3", "TestCase5", "TestCase6", "TestCase7", "TestCase25", "SingleAreaLight", "DoubleLight", "MirrorAndAreaLight",
-          "MirrorBalls", "MetalRings"]  # MetalRings: 30 558 triangles, Phong, two area lights — largest lit model present
+          "MirrorBalls", "MetalRings",  # MetalRings: 30 558 triangles, Phong, two area lights — largest lit model present
+          # every other lit model of the reference below 1 MB as a fixture (parity corpus: sun lights, glass, Phong, mirrors)
+          "IndirectCubeEye", "IndirectCubeH25", "IndirectCubeHalf", "IndirectCubeIOR1", "IndirectCubeIOR2", "IndirectCubeLens1",
+          "IndirectCubeNone", "IndirectSphereIOR2", "LightNoOcclusionTest", "LightOverBox", "LightPathNone", "LightPathShaded",
+          "RandomNumberGeneratorTest", "SimpleCubeIOR1", "SimpleSphereEmpty", "SimpleSphereIOR1", "SimpleSphereIOR2",
+          "TestCase4", "TestCase8", "TestCase9", "TestCase10", "TestCase11", "TestCase12", "TestCase13", "TestCase14", "TestCase15",
+          "TestCase16", "TestCase17", "TestCase18", "TestCase23", "TestCase24", "TestCase27", "TestCase29", "TestCase30", "TestCase31",
+          "TestCase32", "TestCase33", "TestCase35", "TestCase37", "TestCase38", "TestCase39", "TestCase41", "TransparentBoxAndSphere"]
 
 # LivingRoom.blend (43 944 triangles, the largest model present) has no lamps; the reference cannot light it with PT
 # either.  The fixture keeps its geometry, materials and camera and adds ONE area light under the ceiling lamp.

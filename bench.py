@@ -25,8 +25,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def algorithmic_bytes_per_sample(st):
-    """SURVEY.md 8(d), megakernel form (no 192 B path-state term):
+def algorithmic_bytes_per_sample(st, wavefront=False):
+    """megakernel form (no path-state term) or wavefront form (+192 B of path state per segment):
     B = 152*h + 64*(N + N'*s) + 48*(T + T'*s) + 32*s + 16/Lbar   per path segment, where the
     visit counts come from the instrumented kernel variant on the same workload."""
     seg = float(st.num_basic_rays)
@@ -35,7 +35,7 @@ def algorithmic_bytes_per_sample(st):
     lbar = seg / float(st.num_paths)
     n_c, t_c = st.nodes_closest / seg, st.tris_closest / seg
     n_s, t_s = st.nodes_shadow / seg, st.tris_shadow / seg  # already per segment (= N' * s, T' * s)
-    b = 152.0 * h + 64.0 * (n_c + n_s) + 48.0 * (t_c + t_s) + 32.0 * s + 16.0 / lbar
+    b = 152.0 * h + 64.0 * (n_c + n_s) + 48.0 * (t_c + t_s) + 32.0 * s + 16.0 / lbar + (192.0 if wavefront else 0.0)
     eff_c = (st.nodes_closest + st.tris_closest) / (64.0 * st.wave_steps_closest) if st.wave_steps_closest else None
     eff_s = (st.nodes_shadow + st.tris_shadow) / (64.0 * st.wave_steps_shadow) if st.wave_steps_shadow else None
     return b, dict(h=h, s=s, Lbar=lbar, N=n_c, T=t_c, N_shadow_per_segment=n_s, T_shadow_per_segment=t_s,
@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
     ap.add_argument("--max-path", type=int, default=8, help="0 = unlimited (roulette-terminated), the reference default")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 LDS-resident scene, 2 scene in HBM")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 megakernel with the scene in LDS, 2 megakernel with the scene in HBM, 3 wavefront pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses N ranks on one GPU")
@@ -174,7 +174,7 @@ def main():
         pt.set_instrumented(True)
         ist = pt.render_device(fb.data_ptr(), W, H, spp=min(args.spp, 64), seed=seed, sample_offset=0, stream=stream, want_stats=True)
         pt.set_instrumented(False)
-        b_sample, terms = algorithmic_bytes_per_sample(ist)
+        b_sample, terms = algorithmic_bytes_per_sample(ist, wavefront=pt.get_kernel() == ma.KERNEL_WAVEFRONT)
         seg_per_launch = float(st.num_basic_rays)
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = b_sample * seg_per_launch / (avg_ms * 1e-3) / 1e9
@@ -197,12 +197,12 @@ def main():
                            args.scene + (".blend" if ":" not in args.scene and args.scene not in ("atrium", "clutter") else " (procedural stand-in)"), W, H, args.spp,
                            "unlimited" if args.max_path >= ma.PTRDIFF_MAX else args.max_path,
                            " (BASELINE configs[1])" if (args.scene, W, H, args.spp, args.max_path) == ("CornellBoxDiffuse", 512, 512, 1024, 8) else ""),
-                       "kernel": {1: "pt_megakernel<LDS scene>", 2: "pt_megakernel<HBM scene>"}[pt.get_kernel()],
+                       "kernel": {1: "pt_megakernel<LDS scene>", 2: "pt_megakernel<HBM scene>", 3: "wavefront pipeline (wf_extend / wf_shade / wf_shadow / wf_regen)"}[pt.get_kernel()],
                        "parallelism": "samples sharded over %d GPU(s), RCCL all-reduce of [H][W][4] f32" % world,
                        "Mpaths_per_s": paths / elapsed / 1e6, "Mrays_per_s": (segs + shadow) / elapsed / 1e6,
                        "denom_equals_spp": denom_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "pt_megakernel", "avg_launch_ms": avg_ms,
+                         "traffic": traffic, "kernel": "wavefront pipeline (all kernels of one step)" if pt.get_kernel() == ma.KERNEL_WAVEFRONT else "pt_megakernel", "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_sample": b_sample, "terms": terms, "pmc": pmc,
                          "note": "scene is LDS-resident: the kernel is VALU/latency-bound, not HBM-bound; algorithmic bytes are SURVEY 8(d)'s per-segment figure"},
         }

@@ -189,7 +189,12 @@ const char* mi_pt_last_error(void);
 int mi_pt_abi_version(void);
 
 /* Kernel variant selection (for measurement; default MI_PT_KERNEL_AUTO). */
-enum { MI_PT_KERNEL_AUTO = 0, MI_PT_KERNEL_MEGA_LDS = 1, MI_PT_KERNEL_MEGA_GLOBAL = 2 };
+enum {
+  MI_PT_KERNEL_AUTO = 0,
+  MI_PT_KERNEL_MEGA_LDS = 1,     /* megakernel, scene blob staged into LDS (scenes up to 48 KB)            */
+  MI_PT_KERNEL_MEGA_GLOBAL = 2,  /* megakernel, scene read from HBM                                        */
+  MI_PT_KERNEL_WAVEFRONT = 3     /* wavefront pipeline: path state in HBM, one kernel per ray cast / vertex */
+};
 int mi_pt_set_kernel(mi_pt_handle* h, int kernel);
 int mi_pt_get_kernel(mi_pt_handle* h); /* variant AUTO resolves to for this scene */
 /* 1: render calls run the instrumented kernel variant (same results, plus visit counters). */

@@ -25,7 +25,7 @@ ERR_NAMES = {-1: "INVALID_ARGUMENT", -2: "NO_DEVICE", -3: "OUT_OF_MEMORY", -4: "
 
 BSDF_CAMERA, BSDF_DIFFUSE, BSDF_PHONG, BSDF_REFLECTION, BSDF_TRANSMISSION, BSDF_LIGHT, BSDF_SUN = range(7)
 ENTITY_CAMERA, ENTITY_MESH, ENTITY_LIGHT, ENTITY_EMPTY = range(4)
-KERNEL_AUTO, KERNEL_MEGA_LDS, KERNEL_MEGA_GLOBAL = range(3)
+KERNEL_AUTO, KERNEL_MEGA_LDS, KERNEL_MEGA_GLOBAL, KERNEL_WAVEFRONT = range(4)
 UINT32_MAX = 0xFFFFFFFF
 PTRDIFF_MAX = (1 << 63) - 1
 

@@ -17,6 +17,7 @@ SOURCES = [
     "mi_pt_api.hip",
     "device/pt_kernels.hip",
     "device/bvh_build.hip",
+    "device/wf_kernels.hip",
     "scene_host.cpp",
     "blend_reader.cpp",
     "exr_io.cpp",

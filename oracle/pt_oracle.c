@@ -172,6 +172,7 @@ typedef struct {
 #ifndef ORC_COUNT_NODE /* hooks for tests/lab (tree-quality experiments); empty in the oracle proper */
 #define ORC_COUNT_NODE(closest)
 #define ORC_COUNT_TRI(closest)
+#define ORC_RAY_BEGIN(closest)
 #endif
 #define ORC_STACK 256 /* traversal stack entries; the build aborts on a deeper tree */
 
@@ -485,6 +486,7 @@ static void traverse(const orc_scene* s, v3 org, v3 dir, uint32_t ray_mask, hit_
   /* a NaN direction (TransmissionBSDF past the critical angle, BSDF.cpp:467-504) can hit nothing: every dot product in
    * tri_test is NaN.  Leave before the slab test, whose NaN-ignoring min/max would open every box of the tree. */
   if (dir.x != dir.x || dir.y != dir.y || dir.z != dir.z) return;
+  ORC_RAY_BEGIN(closest);
   v3 inv = V(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
   int32_t stack[ORC_STACK]; int sp = 0;
   int32_t node = 0;

@@ -3,10 +3,17 @@
  * Test infrastructure only (includes the oracle source).  Build: see tests/lab/run_lab.py. */
 #include <stdint.h>
 static __thread uint64_t g_cnt[4]; /* nodes closest, tris closest, nodes shadow, tris shadow */
-#define ORC_COUNT_NODE(closest) (g_cnt[(closest) ? 0 : 2]++)
-#define ORC_COUNT_TRI(closest) (g_cnt[(closest) ? 1 : 3]++)
+/* optional event log: 'C' / 'S' = a closest / shadow ray begins, 'n' = node visit, 'l' = leaf (triangle) test, 'P' = new path */
+static unsigned char* g_log; static uint64_t g_log_n, g_log_cap;
+#define LOG_EV(c) do { if (g_log && g_log_n < g_log_cap) g_log[g_log_n++] = (c); } while (0)
+#define ORC_COUNT_NODE(closest) do { g_cnt[(closest) ? 0 : 2]++; LOG_EV('n'); } while (0)
+#define ORC_COUNT_TRI(closest) do { g_cnt[(closest) ? 1 : 3]++; LOG_EV('l'); } while (0)
+#define ORC_RAY_BEGIN(closest) LOG_EV((closest) ? 'C' : 'S')
 #include "../../oracle/pt_oracle.c"
 
+ORC_API void lab_log(unsigned char* buf, uint64_t cap) { g_log = buf; g_log_cap = cap; g_log_n = 0; }
+ORC_API uint64_t lab_log_size(void) { return g_log_n; }
+ORC_API void lab_log_mark(void) { LOG_EV('P'); }
 ORC_API void lab_counters(uint64_t out[4], int reset) { for (int i = 0; i < 4; ++i) { out[i] = g_cnt[i]; if (reset) g_cnt[i] = 0; } }
 
 /* ---- helpers over the node array ---- */

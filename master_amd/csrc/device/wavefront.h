@@ -12,30 +12,26 @@
 namespace mi {
 
 struct WfState {
-  uint32_t P;                  // path slots in flight
-  uint32_t list;               // 1: work items come from RenderParams::list_* (mi_pt_trace_paths)
-  uint64_t n_items;            // work items of this batch
-  uint64_t batch_sample0;      // first sample index of this batch (added to RenderParams::sample_offset)
-  // per slot (SoA)
+  uint32_t P;                  // path slots = per_sample * R (image mode)
+  uint32_t per_sample;         // pixel slots: tiles * 64 (image mode); P in list mode
+  uint32_t R;                  // sample replicas in flight per pixel
+  uint32_t list;               // 1: work items come from RenderParams::list_* (mi_pt_trace_paths), slot i takes items i + j P
+  uint64_t n_items;            // list mode: number of items
+  // per slot (SoA, thread == slot: coalesced)
   uint64_t* rng;               // PCG state
-  float4* ray_o; float4* ray_d;  // ray origin / direction of the next closest-hit cast
+  float4* ray_o; float4* ray_d;  // next closest-hit ray: origin | slot flags, direction | paths started by this slot
   float4* st_a;                // eye[prv].position | bsdf.density
   float4* st_b;                // throughput numerator (PT.cpp:59-60) | flags: bounce, bsdf.finite, path_size
-  float4* st_c;                // radiance | work item
+  float4* st_c;                // radiance of the path under way
   uint2* cnt;                  // rays cast by this path (closest, shadow) — reported by mi_pt_trace_paths
   float4* hit;                 // t, u, v | Morton position of the triangle (0xFFFFFFFF = miss)
   float4* sh_o; float4* sh_d; float* sh_z;  // shadow ray origin | nee.r, direction (to the target) | nee.g, nee.b
-  // queues of slot indices
-  uint32_t* qc[2];             // closest-hit queue, ping-pong
-  uint32_t* qs;                // shadow queue
-  uint32_t* qf;                // finished paths
-  uint32_t* n;                 // [4]: sizes of qc[0], qc[1], qs, qf
-  unsigned long long* work_next;  // next unclaimed work item
-  float4* results;             // [n_items] per-path radiance | valid (image mode)
+  double4* acc;                // image mode: the slot's FP64 sum over its finished paths (r, g, b, count)
+  unsigned long long* n_active;  // slots still active after wf_shade (read by the host every fourth round)
 };
 
-constexpr size_t kWfBytesPerSlot = 8 + 16 * 8 + 8 + 4 + 4 * 4;  // rng, 8 float4 arrays, cnt, sh_z, 4 queue entries
+constexpr size_t kWfBytesPerSlot = 8 + 16 * 8 + 8 + 4 + 32;  // rng, 8 float4 arrays, cnt, sh_z, acc
 
-hipError_t wf_run_batch(const RenderParams& p, const WfState& w, bool count, uint32_t batch_spp, hipStream_t stream, uint32_t* iterations_out);
+hipError_t wf_run(const RenderParams& p, const WfState& w, bool count, hipStream_t stream, uint32_t* rounds_out);
 
 }  // namespace mi

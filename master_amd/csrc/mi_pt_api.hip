@@ -41,9 +41,8 @@ struct mi_pt_handle {
   unsigned long long* d_counters = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-  // wavefront pipeline: one arena for the per-slot arrays and queues, one for the per-path results of a batch
+  // wavefront pipeline: one arena for the per-slot arrays
   char* wf_arena = nullptr; size_t wf_arena_bytes = 0;
-  float4* wf_results = nullptr; size_t wf_results_bytes = 0;
   uint32_t wf_iterations = 0;
 };
 
@@ -75,37 +74,30 @@ bool use_lds_scene(const mi_pt_handle* h) {
 }
 
 // Carves the wavefront state out of the handle's arena (grown on demand).
-int wf_prepare(mi_pt_handle* h, uint32_t P, uint64_t result_items, mi::WfState& w) {
-  const size_t per_slot = 8 + 16 * 8 + 8 + 4 + 4 * 4;
-  const size_t need = size_t(P) * per_slot + 4096;
+int wf_prepare(mi_pt_handle* h, uint32_t P, mi::WfState& w) {
+  const size_t need = size_t(P) * mi::kWfBytesPerSlot + 16 * 256 + 4096;
   int rc = ensure(reinterpret_cast<void**>(&h->wf_arena), &h->wf_arena_bytes, need);
-  if (rc) return rc;
-  rc = ensure(reinterpret_cast<void**>(&h->wf_results), &h->wf_results_bytes, size_t(result_items ? result_items : 1) * 16);
   if (rc) return rc;
   char* a = h->wf_arena;
   auto take = [&](size_t bytes) { char* r = a; a += (bytes + 255) / 256 * 256; return r; };
   std::memset(&w, 0, sizeof w);
   w.P = P;
-  w.n = reinterpret_cast<uint32_t*>(take(16));
-  w.work_next = reinterpret_cast<unsigned long long*>(take(8));
+  w.n_active = reinterpret_cast<unsigned long long*>(take(8));
+  w.acc = reinterpret_cast<double4*>(take(size_t(P) * 32));
   w.ray_o = reinterpret_cast<float4*>(take(size_t(P) * 16)); w.ray_d = reinterpret_cast<float4*>(take(size_t(P) * 16));
   w.st_a = reinterpret_cast<float4*>(take(size_t(P) * 16)); w.st_b = reinterpret_cast<float4*>(take(size_t(P) * 16));
   w.st_c = reinterpret_cast<float4*>(take(size_t(P) * 16)); w.hit = reinterpret_cast<float4*>(take(size_t(P) * 16));
   w.sh_o = reinterpret_cast<float4*>(take(size_t(P) * 16)); w.sh_d = reinterpret_cast<float4*>(take(size_t(P) * 16));
   w.rng = reinterpret_cast<uint64_t*>(take(size_t(P) * 8)); w.cnt = reinterpret_cast<uint2*>(take(size_t(P) * 8));
   w.sh_z = reinterpret_cast<float*>(take(size_t(P) * 4));
-  w.qc[0] = reinterpret_cast<uint32_t*>(take(size_t(P) * 4)); w.qc[1] = reinterpret_cast<uint32_t*>(take(size_t(P) * 4));
-  w.qs = reinterpret_cast<uint32_t*>(take(size_t(P) * 4)); w.qf = reinterpret_cast<uint32_t*>(take(size_t(P) * 4));
   if (size_t(a - h->wf_arena) > h->wf_arena_bytes) return fail(MI_ERR_INTERNAL, "wavefront arena too small");
-  w.results = h->wf_results;
   return MI_OK;
 }
 
-uint32_t wf_slots(uint64_t items) {
-  uint64_t P = 1ull << 21;  // 2 M paths in flight (330 MB of state): ~8 k waves per kernel launch
+uint64_t wf_target_slots() {
+  uint64_t P = 1ull << 21;  // ~2 M paths in flight (~400 MB of state): 8 k waves per kernel launch
   if (const char* e = std::getenv("MI_PT_WF_SLOTS")) { const long long v = std::atoll(e); if (v >= 256) P = uint64_t(v); }
-  if (P > items) P = (items + 255) / 256 * 256;
-  return uint32_t(P < 256 ? 256 : P);
+  return P;
 }
 
 int fill_camera(const mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi::RenderParams& p) {
@@ -286,7 +278,6 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->d_morton) hipFree(h->d_morton);
   if (h->partial) hipFree(h->partial);
   if (h->wf_arena) hipFree(h->wf_arena);
-  if (h->wf_results) hipFree(h->wf_results);
   if (h->d_rgbn) hipFree(h->d_rgbn);
   if (h->d_counters) hipFree(h->d_counters);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -332,15 +323,16 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
   p.tiles_x = (win.w + 7) / 8; p.tiles_y = (win.h + 7) / 8;
   const uint64_t n_tiles = uint64_t(p.tiles_x) * p.tiles_y;
   if (h->kernel_choice == MI_PT_KERNEL_WAVEFRONT) {
-    // batches of whole samples: per-path results of a batch (16 B each, <= 512 MB) are summed per pixel in sample order
+    // slot i = pixel slot i % per_sample, replica i / per_sample: R replicas of every pixel are in flight
     const uint64_t per_sample = n_tiles * 64ull;
-    if (per_sample > 0xFFFFFFFFull) return fail(MI_ERR_UNSUPPORTED, "render too large for the wavefront pipeline");
-    uint64_t batch_spp = (32ull << 20) / per_sample;
-    if (batch_spp < 1) batch_spp = 1;
-    if (batch_spp > spp) batch_spp = spp;
+    uint64_t R = (wf_target_slots() + per_sample / 2) / per_sample;
+    if (R < 1) R = 1;
+    if (R > spp) R = spp;
+    if (per_sample * R > 0xFFFFFF00ull) return fail(MI_ERR_UNSUPPORTED, "render too large for the wavefront pipeline");
     mi::WfState w;
-    rc = wf_prepare(h, wf_slots(per_sample * batch_spp), per_sample * batch_spp, w);
+    rc = wf_prepare(h, uint32_t(per_sample * R), w);
     if (rc) return rc;
+    w.per_sample = uint32_t(per_sample); w.R = uint32_t(R); w.list = 0; w.n_items = 0;
     rc = ensure(reinterpret_cast<void**>(&h->partial), &h->partial_bytes, size_t(width) * height * 32);
     if (rc) return rc;
     p.partial = h->partial; p.counters = h->d_counters; p.n_chunks = 1; p.chunk_spp = spp;
@@ -349,11 +341,7 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
     HIP_TRY(hipEventRecord(h->ev0, stream));
     HIP_TRY(hipMemsetAsync(h->partial, 0, size_t(width) * height * 32, stream));
     h->wf_iterations = 0;
-    for (uint64_t s0 = 0; s0 < spp; s0 += batch_spp) {
-      const uint64_t bs = s0 + batch_spp <= spp ? batch_spp : spp - s0;
-      w.batch_sample0 = s0; w.n_items = per_sample * bs; w.list = 0;
-      HIP_TRY(mi::wf_run_batch(p, w, h->instrumented, uint32_t(bs), stream, &h->wf_iterations));
-    }
+    HIP_TRY(mi::wf_run(p, w, h->instrumented, stream, &h->wf_iterations));
     HIP_TRY(hipEventRecord(h->ev1, stream));
     HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, 1, stream));
     HIP_TRY(hipEventRecord(h->ev2, stream));
@@ -491,12 +479,14 @@ int mi_pt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint3
   p.counters = nullptr;
   if (h->kernel_choice == MI_PT_KERNEL_WAVEFRONT) {
     mi::WfState w;
-    rc = wf_prepare(h, wf_slots(n), 0, w);
+    uint64_t P = wf_target_slots();
+    if (P > n) P = (uint64_t(n) + 255) / 256 * 256;
+    rc = wf_prepare(h, uint32_t(P), w);
     if (rc) return rc;
-    w.list = 1; w.n_items = n; w.batch_sample0 = 0;
+    w.list = 1; w.n_items = n; w.per_sample = w.P; w.R = 1;
     p.counters = h->d_counters;
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), h->stream));
-    HIP_TRY(mi::wf_run_batch(p, w, false, 0, h->stream, nullptr));
+    HIP_TRY(mi::wf_run(p, w, false, h->stream, nullptr));
   } else {
     const uint32_t per_block = 4u * 64u * 16u;
     HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), true, false, (n + per_block - 1) / per_block, h->stream));

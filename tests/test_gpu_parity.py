@@ -127,7 +127,7 @@ def test_parameters_follow_the_reference_semantics(cornell, beta, roulette, ligh
         np.testing.assert_allclose(gr, orr, rtol=2e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("kernel", [ma.KERNEL_MEGA_LDS, ma.KERNEL_MEGA_GLOBAL])
+@pytest.mark.parametrize("kernel", [ma.KERNEL_MEGA_LDS, ma.KERNEL_MEGA_GLOBAL, ma.KERNEL_WAVEFRONT])
 @pytest.mark.parametrize("w,h,spp,window", [(64, 64, 8, None), (37, 23, 5, None), (64, 48, 3, (5, 7, 21, 30)), (8, 8, 1, None), (1, 1, 64, None), (130, 9, 2, (120, 0, 10, 9))])
 def test_render_equals_oracle(cornell, kernel, w, h, spp, window):
     """Technique::render for spp frames: image, denominators and ray counters (ragged sizes, windows)."""
@@ -152,6 +152,9 @@ def test_both_kernel_variants_agree_and_runs_are_deterministic(cornell):
     pt.set_kernel(ma.KERNEL_MEGA_GLOBAL); b = pt.render_rgbn(96, 96, spp=32, seed=9)
     assert np.array_equal(a[..., 3], b[..., 3])
     np.testing.assert_allclose(a, a2, rtol=1.2e-7); np.testing.assert_allclose(a, b, rtol=1.2e-7)
+    pt.set_kernel(ma.KERNEL_WAVEFRONT); w = pt.render_rgbn(96, 96, spp=32, seed=9); w2 = pt.render_rgbn(96, 96, spp=32, seed=9)
+    assert pt.get_kernel() == ma.KERNEL_WAVEFRONT and np.array_equal(w, w2) and np.array_equal(a[..., 3], w[..., 3])
+    np.testing.assert_allclose(a, w, rtol=1.2e-7)
     c = pt.render_rgbn(96, 96, spp=32, seed=10)
     assert not np.array_equal(a, c)
 
@@ -278,6 +281,31 @@ def test_phong_scene_within_stated_tolerance():
     assert close.mean() > 0.995, close.mean()
     img = pt.render_rgbn(64, 64, spp=64, seed=1)[..., :3] / 64; ref = orc.render_rgbn(64, 64, spp=64, seed=1)[..., :3] / 64
     assert abs(img.mean() - ref.mean()) / ref.mean() < 2e-3
+
+
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxSpecular", "TestCaseFurnace", "MirrorBalls", "TestCase27", "MetalRings", "single"])
+def test_wavefront_pipeline_is_bit_identical_per_path(name):
+    """The wavefront kernels run the same device functions in the same order as the megakernel: radiance and ray counts
+    of every path agree bit for bit (Phong included: same pow on both sides), also when a slot renders many paths in a row."""
+    s = get_scene(name)
+    a, b = ma.PathTracing(s), ma.PathTracing(s)
+    b.set_kernel(ma.KERNEL_WAVEFRONT)
+    rng = np.random.default_rng(23); n = 30000
+    xy = np.stack([rng.integers(0, 96, n), rng.integers(0, 54, n)], 1).astype(np.uint32); si = rng.integers(0, 64, n).astype(np.uint64)
+    ra, ca = a.trace_paths(96, 54, xy, si, seed=13); rb, cb = b.trace_paths(96, 54, xy, si, seed=13)
+    assert np.array_equal(ca, cb)
+    assert ((ra.view(np.uint32) == rb.view(np.uint32)) | (np.isnan(ra) & np.isnan(rb))).all()
+    os.environ["MI_PT_WF_SLOTS"] = "1024"  # few slots: every slot renders ~30 paths one after the other
+    try:
+        rc, cc = b.trace_paths(96, 54, xy, si, seed=13)
+    finally:
+        del os.environ["MI_PT_WF_SLOTS"]
+    assert np.array_equal(ca, cc) and ((ra.view(np.uint32) == rc.view(np.uint32)) | (np.isnan(ra) & np.isnan(rc))).all()
+    ia = a.render_rgbn(160, 90, spp=24, seed=3); ib = b.render_rgbn(160, 90, spp=24, seed=3)
+    assert np.array_equal(ia[..., 3], ib[..., 3])
+    np.testing.assert_allclose(ia, ib, rtol=1.2e-7)
+    sa, sb_ = a.last_stats, b.last_stats
+    assert (sa.num_paths, sa.num_basic_rays, sa.num_shadow_rays, sa.numeric_errors) == (sb_.num_paths, sb_.num_basic_rays, sb_.num_shadow_rays, sb_.numeric_errors)
 
 
 def _corpus():

@@ -39,6 +39,7 @@ MI_DEV uint32_t wave_sum(uint32_t v) {
 #define MI_STAMP(k) do { } while (0)
 #endif
 
+constexpr uint32_t kLargeSceneTris = 100000u;
 constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums, counts, 8 instrumentation words
 
 #ifndef MI_FUSED_TRAVERSAL
@@ -57,11 +58,14 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 #define MI_WAVES_LDS 6
 #endif
 #ifndef MI_WAVES_HBM
-#define MI_WAVES_HBM 5  // HBM-resident scenes: 3, 4, 5 waves within 1 %, 6 waves -6 %, 8 waves -10..-30 % (atrium 270k, CornellBoxSpecular)
+#define MI_WAVES_HBM 6  // HBM-resident scenes (profiles/r01/ab_launch_bounds.txt): 6 waves = 5 waves +-1 % on small scenes, +3..9 % on 150-270 k triangles
+#endif
+#ifndef MI_WAVES_HBM_LARGE
+#define MI_WAVES_HBM_LARGE 7  // scenes of >= kLargeSceneTris triangles: latency-bound gathers want occupancy (atrium +12 %, clutter +4 % over 5 waves); -11 % on a 2 k-triangle scene
 #endif
 
-template <bool LDS_SCENE, bool LIST, bool COUNT>
-__global__ __launch_bounds__(kBlock, LDS_SCENE ? MI_WAVES_LDS : MI_WAVES_HBM) void pt_megakernel(const RenderParams p) {
+template <bool LDS_SCENE, bool LIST, bool COUNT, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParams p) {
   extern __shared__ float4 smem[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -460,9 +464,11 @@ size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream) {
   const size_t lds = pt_lds_bytes(p, lds_scene);
   void (*fn)(const RenderParams) = nullptr;
-  if (count) fn = lds_scene ? pt_megakernel<true, false, true> : pt_megakernel<false, false, true>;
-  else if (lds_scene) fn = list ? pt_megakernel<true, true, false> : pt_megakernel<true, false, false>;
-  else fn = list ? pt_megakernel<false, true, false> : pt_megakernel<false, false, false>;
+  const bool large = p.sv.n_tris >= kLargeSceneTris;
+  if (count) fn = lds_scene ? pt_megakernel<true, false, true, MI_WAVES_LDS> : (large ? pt_megakernel<false, false, true, MI_WAVES_HBM_LARGE> : pt_megakernel<false, false, true, MI_WAVES_HBM>);
+  else if (lds_scene) fn = list ? pt_megakernel<true, true, false, MI_WAVES_LDS> : pt_megakernel<true, false, false, MI_WAVES_LDS>;
+  else if (large) fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM_LARGE> : pt_megakernel<false, false, false, MI_WAVES_HBM_LARGE>;
+  else fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM> : pt_megakernel<false, false, false, MI_WAVES_HBM>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(kBlock), lds, stream, p);

@@ -112,7 +112,9 @@ struct TravStack {
 // are only live in the instrumented kernel variant (COUNT) and compile away otherwise.
 struct Visits { uint32_t nodes, tris; uint32_t* wave_iters; };  // wave_iters: LDS [2] per wave: node-loop bodies, leaf-phase bodies (instrumented)
 
-template <bool ANY, bool COUNT = false, bool QUANT = false>
+// NS = node stride in float4 units: 4 in HBM; the LDS copy pads nodes to 5 (80 B) so that lanes reading the same field of
+// different nodes spread over all 32 banks instead of 2 groups of 4 (64 B = 16 banks: every other node collides).
+template <bool ANY, bool COUNT = false, bool QUANT = false, int NS = 4>
 MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 org, f3 dir,
                      uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
   const float4* nodes = sb + sv.off_nodes;
@@ -142,7 +144,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravSta
         hi1 = F3(float(b.y >> 16), float(b.z & 0xFFFFu), float(b.z >> 16));
         l0 = int(a.w); l1 = int(b.w);
       } else {
-        const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+        const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
         lo0 = xyz(n0); hi0 = xyz(n1); lo1 = xyz(n2); hi1 = xyz(n3);
         l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
       }
@@ -172,10 +174,12 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravSta
   }
 }
 
-// Scene::querySurface (Scene.cpp:80-126)
+// Scene::querySurface (Scene.cpp:80-126).  SS = shading-record stride in float4 units (8 in HBM, 9 in the padded LDS copy:
+// with 128-byte records every lane's k-th float4 falls into the same 4 LDS banks).
+template <int SS = 8>
 MI_DEV Surf query_surface(const float4* __restrict__ sb, const SceneView& sv, f3 org, f3 dir, const Hit& h) {
   Surf p;
-  const float4* sh = sb + sv.off_shade + 8 * h.pos;
+  const float4* sh = sb + sv.off_shade + SS * h.pos;
   const float4 q0 = sh[0], q1 = sh[1], q2 = sh[2], q3 = sh[3], q4 = sh[4], q5 = sh[5], q6 = sh[6], q7 = sh[7];
   const float w = 1.f - h.u - h.v;
   const float u = h.u, v = h.v;

@@ -70,12 +70,21 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
-  const SceneView sv = p.sv;
+  SceneView sv = p.sv;
 
-  const uint32_t blob_f4 = LDS_SCENE ? sv.blob_f4 : 0u;
+  // LDS copy of the scene blob with padded records (nodes 64 -> 80 B, shading records 128 -> 144 B): power-of-two strides
+  // put the same field of every record into the same few banks
+  constexpr int NS = LDS_SCENE ? 5 : 4, SS = LDS_SCENE ? 9 : 8;
+  const uint32_t blob_f4 = LDS_SCENE ? sv.blob_f4 + sv.n_nodes + sv.n_tris : 0u;
   const float4* sb = sv.blob;
   if (LDS_SCENE) {
-    for (uint32_t i = tid; i < blob_f4; i += kBlock) smem[i] = sv.blob[i];
+    const uint32_t o_tris = sv.n_nodes * 5u, o_shade = o_tris + sv.n_tris * 3u, o_rest = o_shade + sv.n_tris * 9u;
+    for (uint32_t i = tid; i < sv.n_nodes * 4u; i += kBlock) smem[(i >> 2) * 5u + (i & 3u)] = sv.blob[sv.off_nodes + i];
+    for (uint32_t i = tid; i < sv.n_tris * 3u; i += kBlock) smem[o_tris + i] = sv.blob[sv.off_tris + i];
+    for (uint32_t i = tid; i < sv.n_tris * 8u; i += kBlock) smem[o_shade + (i >> 3) * 9u + (i & 7u)] = sv.blob[sv.off_shade + i];
+    for (uint32_t i = tid; i < sv.blob_f4 - sv.off_mats; i += kBlock) smem[o_rest + i] = sv.blob[sv.off_mats + i];
+    sv.off_lights = o_rest + (sv.off_lights - sv.off_mats); sv.off_cdf = o_rest + (sv.off_cdf - sv.off_mats);
+    sv.off_nodes = 0u; sv.off_tris = o_tris; sv.off_shade = o_shade; sv.off_mats = o_rest;
     sb = smem;
   }
   TravStack stack;
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
 #else
       h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
       const uint32_t steps0 = vis_c.nodes + vis_c.tris;
-      traverse<false, COUNT, !LDS_SCENE && MI_QUANT_NODES>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
+      traverse<false, COUNT, !LDS_SCENE && MI_QUANT_NODES, NS>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
 #endif
       MI_STAMP(1);  // closest-hit traversal
       ++path_basic;
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
       if (h.id == 0xFFFFFFFFu) {
         terminate = true;  // PT.cpp:28,49-51: a miss ends the path (PT ignores the sky)
       } else {
-        sp = query_surface(sb, sv, org, dir, h);
+        sp = query_surface<SS>(sb, sv, org, dir, h);
         const bool is_light = surf_is_light(sp);
         if (!bounce) {
           if (is_light && p.max_path > 0u) {  // PT.cpp:23-26: directly visible light, continue through it
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
           const uint32_t s0 = vis_s.nodes + vis_s.tris;
-          traverse<true, COUNT, !LDS_SCENE && MI_QUANT_NODES>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
+          traverse<true, COUNT, !LDS_SCENE && MI_QUANT_NODES, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
           if (COUNT) steps_mine_s = vis_s.nodes + vis_s.tris - s0;
           radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
           pending = false;
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         // the shadow ray is traversed after the BSDF sample so that the surface frame and the material are dead by now
         if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
-          traverse<true, COUNT, !LDS_SCENE && MI_QUANT_NODES>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
+          traverse<true, COUNT, !LDS_SCENE && MI_QUANT_NODES, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
           radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
           pending = false;
         }
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
 
 // ---- host-callable launchers (declared in launch.h) ----
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
-  return (lds_scene ? size_t(p.sv.blob_f4) * 16 : 0) + size_t(p.stack_entries) * kBlock * 4 + 4 * kAccBytesPerWave;
+  return (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0) + size_t(p.stack_entries) * kBlock * 4 + 4 * kAccBytesPerWave;
 }
 
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream) {

@@ -263,7 +263,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     if (need > se + 64u) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack (12 LDS + 64 spill entries)");
     h->info.stack_entries = se;
   }
-  h->lds_fits = size_t(sv.blob_f4) * 16 <= kLdsSceneLimit;
+  h->lds_fits = size_t(sv.blob_f4 + sv.n_nodes + sv.n_tris) * 16 <= kLdsSceneLimit;  // the LDS copy pads nodes and shading records by one float4
   guard.h = nullptr;
   *out = h;
   return MI_OK;

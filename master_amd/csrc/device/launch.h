@@ -12,16 +12,16 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
                      mi_bvh_node* nodes, float4* tri_isect, float4* tri_shade, uint32_t* sorted_tri, uint64_t* morton,
                      float scene_lo[3], float scene_hi[3], uint32_t* max_depth_out, float* build_ms, uint32_t* rounds_out, hipStream_t stream);
 
-hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, const float lo[3], const float inv_step[3],
+hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, uint4* qnodes4, const float lo[3], const float inv_step[3],
                           hipStream_t stream);
 
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene);
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_finalize(const double* partial, float* rgbn, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w,
                            uint32_t h, uint32_t n_chunks, hipStream_t stream);
-hipError_t launch_intersect(const SceneView& sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* origins, const float* dirs,
+hipError_t launch_intersect(const SceneView& sv, bool wide, uint32_t stack_entries, uint32_t n, const mi_surface_point* origins, const float* dirs,
                             mi_surface_point* out_hits, float* out_t, uint32_t* out_prim, hipStream_t stream);
-hipError_t launch_occluded(const SceneView& sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* a, const mi_surface_point* b,
+hipError_t launch_occluded(const SceneView& sv, bool wide, uint32_t stack_entries, uint32_t n, const mi_surface_point* a, const mi_surface_point* b,
                            float* out, hipStream_t stream);
 
 }  // namespace mi

@@ -23,6 +23,9 @@ struct SceneView {
   // quantised copy of the BVH2 nodes for HBM-resident scenes: 32 B per node (two child boxes as 12 x u16 on a
   // 65536^3 grid over the scene box, rounded outward by one cell, + two links) — half the bytes per visited node
   const uint4* qnodes;
+  // wide quantised nodes, indexed like the BVH2 nodes (only even-depth entries are valid): 4 x (child box as 6 x u16 + link),
+  // the grandchildren of the BVH2 node — 64 B per visited node, half as many dependent fetches per ray
+  const uint4* qnodes4;
   float grid_lo[3];
   float grid_inv_step[3];  // cells per world unit
 };
@@ -49,6 +52,7 @@ struct RenderParams {
   uint32_t win_x0, win_y0, win_w, win_h;
   uint32_t tiles_x, tiles_y;
   uint32_t stack_entries;  // per-lane traversal stack capacity (LDS), >= BVH depth
+  uint32_t wide_nodes;     // HBM-resident kernels: 1 = walk the 64-byte wide nodes with the 7-wave register budget (large scenes)
   // sample range
   uint32_t spp, n_chunks, chunk_spp;
   uint64_t seed, sample_offset;

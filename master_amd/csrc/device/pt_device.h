@@ -90,7 +90,8 @@ MI_DEV bool box_test(f3 lo, f3 hi, const RayBox& rb, float tmax, float& tnear) {
 // Per-lane traversal stack: the first `cap` levels live in LDS (stack[level * kBlock + tid]: consecutive
 // lanes hit consecutive banks); deeper levels — rare, traversal keeps few far children pending — go to a
 // private (scratch) array, so LDS per workgroup stays at `cap` KB however deep the LBVH is.
-constexpr uint32_t kStackSpill = 64;
+constexpr uint32_t kStackSpill = 128;
+constexpr int kEmptyLink = 0x7FFFFFFF;  // unused child slot of a wide node
 // The LDS part is addressed through an address-space-3 pointer: with a generic pointer the compiler cannot prove the
 // target is LDS next to the private spill array and falls back to FLAT loads/stores with 64-bit address arithmetic
 // on the pop -> next-node critical path; this way push/pop are ds_write_b32 / ds_read_b32.
@@ -114,7 +115,7 @@ struct Visits { uint32_t nodes, tris; uint32_t* wave_iters; };  // wave_iters: L
 
 // NS = node stride in float4 units: 4 in HBM; the LDS copy pads nodes to 5 (80 B) so that lanes reading the same field of
 // different nodes spread over all 32 banks instead of 2 groups of 4 (64 B = 16 banks: every other node collides).
-template <bool ANY, bool COUNT = false, bool QUANT = false, int NS = 4>
+template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4>
 MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 org, f3 dir,
                      uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
   const float4* nodes = sb + sv.off_nodes;
@@ -132,6 +133,45 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravSta
   const uint4* __restrict__ qn = sv.qnodes;
   int sp = 0;
   int node = 0;
+  if (QUANT == 2) {
+    // ---- wide quantised nodes: one 64-byte record = the (up to) four grandchildren of an even-depth BVH2 node.  Half as
+    // many dependent fetches per ray as the binary walk; the far children are pushed farthest first. ----
+    const uint4* __restrict__ q4 = sv.qnodes4;
+    for (;;) {
+      if (node >= 0) {
+        float t[4]; int l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint4 a = q4[4 * node + k];
+          const f3 lo = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
+          const f3 hi = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
+          float tn;
+          const bool hk = box_test(lo, hi, rb, h.t, tn) && int(a.w) != kEmptyLink;
+          t[k] = hk ? tn : __builtin_inff();
+          l[k] = int(a.w);
+        }
+        if (COUNT) { ++vis->nodes; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[0], 1u); }
+#define MI_CSWAP(a, b) do { const bool s_ = t[b] < t[a]; const float ta_ = s_ ? t[b] : t[a], tb_ = s_ ? t[a] : t[b]; \
+                            const int la_ = s_ ? l[b] : l[a], lb_ = s_ ? l[a] : l[b]; t[a] = ta_; t[b] = tb_; l[a] = la_; l[b] = lb_; } while (0)
+        MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); MI_CSWAP(1, 3); MI_CSWAP(1, 2);
+#undef MI_CSWAP
+        if (t[0] < __builtin_inff()) {
+          if (t[3] < __builtin_inff()) { stack.push(sp, uint32_t(l[3])); ++sp; }
+          if (t[2] < __builtin_inff()) { stack.push(sp, uint32_t(l[2])); ++sp; }
+          if (t[1] < __builtin_inff()) { stack.push(sp, uint32_t(l[1])); ++sp; }
+          node = l[0];
+          continue;
+        }
+      } else {
+        if (COUNT) { ++vis->tris; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[1], 1u); }
+        const bool hit = tri_test<ANY>(tris, uint32_t(~node), org, dir, ray_mask, h);
+        if (ANY && hit) return;
+      }
+      if (sp == 0) return;
+      --sp;
+      node = int(stack.pop(sp));
+    }
+  }
   for (;;) {
     if (node >= 0) {
       f3 lo0, hi0, lo1, hi1;
@@ -211,7 +251,7 @@ MI_DEV f3 nudge(f3 position, f3 gnormal, f3 dir) {
 }
 
 // Scene::occluded (Scene.cpp:151-180): 1 = visible.
-template <bool COUNT = false, bool QUANT = false>
+template <bool COUNT = false, int QUANT = 0>
 MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 opos, f3 ognormal, f3 tpos,
                       f3 tgnormal, Visits* vis = nullptr) {
   const f3 direction = tpos - opos;  // Scene.cpp:153 normalises; only signs are used

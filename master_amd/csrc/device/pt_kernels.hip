@@ -39,7 +39,6 @@ MI_DEV uint32_t wave_sum(uint32_t v) {
 #define MI_STAMP(k) do { } while (0)
 #endif
 
-constexpr uint32_t kLargeSceneTris = 100000u;
 constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums, counts, 8 instrumentation words
 
 #ifndef MI_FUSED_TRAVERSAL
@@ -51,9 +50,10 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 // Second __launch_bounds__ argument = minimum waves per SIMD the register budget must allow.  Measured on
 // CornellBoxDiffuse (LDS-resident scene): 3 waves 6.1, 4 waves 7.1, 5 waves 7.7, 6 waves 8.1, 8 waves 6.7 Gsamples/s
 // (profiles/r01/ab_launch_bounds.txt); the 6-wave build spills 136 B/lane to scratch and still wins on latency hiding.
-#ifndef MI_QUANT_NODES
-#define MI_QUANT_NODES 1  // kernels that read the scene from HBM walk the 32-byte quantised nodes
-#endif
+// Kernels that read the scene from HBM walk quantised nodes: QN = 1 the 32-byte binary nodes, QN = 2 the 64-byte wide nodes
+// (four grandchildren per record).  Wide nodes halve the dependent fetches per ray: +9 % on 270 k triangles, +5 % on 158 k,
+// but -3..-12 % on scenes of 2-44 k triangles whose nodes sit in L2 (profiles/r01/ab_bvh4.txt) — chosen per scene
+// (RenderParams::wide_nodes; default: scenes of >= 100 000 triangles, together with the 7-wave register budget).
 #ifndef MI_WAVES_LDS
 #define MI_WAVES_LDS 6
 #endif
@@ -64,7 +64,7 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 #define MI_WAVES_HBM_LARGE 7  // scenes of >= kLargeSceneTris triangles: latency-bound gathers want occupancy (atrium +12 %, clutter +4 % over 5 waves); -11 % on a 2 k-triangle scene
 #endif
 
-template <bool LDS_SCENE, bool LIST, bool COUNT, int WAVES>
+template <bool LDS_SCENE, bool LIST, bool COUNT, int WAVES, int QN>
 __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParams p) {
   extern __shared__ float4 smem[];
   const uint32_t tid = threadIdx.x;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
 #else
       h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
       const uint32_t steps0 = vis_c.nodes + vis_c.tris;
-      traverse<false, COUNT, !LDS_SCENE && MI_QUANT_NODES, NS>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
+      traverse<false, COUNT, QN, NS>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
 #endif
       MI_STAMP(1);  // closest-hit traversal
       ++path_basic;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
           const uint32_t s0 = vis_s.nodes + vis_s.tris;
-          traverse<true, COUNT, !LDS_SCENE && MI_QUANT_NODES, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
+          traverse<true, COUNT, QN, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
           if (COUNT) steps_mine_s = vis_s.nodes + vis_s.tris - s0;
           radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
           pending = false;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         // the shadow ray is traversed after the BSDF sample so that the surface frame and the material are dead by now
         if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
-          traverse<true, COUNT, !LDS_SCENE && MI_QUANT_NODES, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
+          traverse<true, COUNT, QN, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
           radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
           pending = false;
         }
@@ -415,6 +415,7 @@ __global__ __launch_bounds__(256) void pt_finalize(const double* __restrict__ pa
 }
 
 // Batched Scene::intersect + querySurface (parity hook, mi_pt_intersect).
+template <int QN>
 __global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* __restrict__ origins,
                                                      const float* __restrict__ dirs, mi_surface_point* __restrict__ out_hits,
                                                      float* __restrict__ out_t, uint32_t* __restrict__ out_prim) {
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t sta
   const f3 dir = F3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
   const f3 org = nudge(pos, gn, dir);
   Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-  traverse<false, false, MI_QUANT_NODES != 0>(sv.blob, sv, stack, org, dir, 0xFFFFFFFFu, h);
+  traverse<false, false, QN>(sv.blob, sv, stack, org, dir, 0xFFFFFFFFu, h);
   if (out_t) out_t[i] = h.t;
   if (out_prim) out_prim[i] = h.id;
   if (out_hits) {
@@ -452,6 +453,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t sta
 }
 
 // Batched Scene::occluded (parity hook, mi_pt_occluded).
+template <int QN>
 __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* __restrict__ a,
                                                     const mi_surface_point* __restrict__ b, float* __restrict__ out) {
   extern __shared__ float4 smem[];
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
   stack.cap = stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  out[i] = occluded<false, MI_QUANT_NODES != 0>(sv.blob, sv, stack, F3(a[i].position[0], a[i].position[1], a[i].position[2]),
+  out[i] = occluded<false, QN>(sv.blob, sv, stack, F3(a[i].position[0], a[i].position[1], a[i].position[2]),
                     F3(a[i].gnormal[0], a[i].gnormal[1], a[i].gnormal[2]), F3(b[i].position[0], b[i].position[1], b[i].position[2]),
                     F3(b[i].gnormal[0], b[i].gnormal[1], b[i].gnormal[2]));
 }
@@ -473,11 +475,11 @@ size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream) {
   const size_t lds = pt_lds_bytes(p, lds_scene);
   void (*fn)(const RenderParams) = nullptr;
-  const bool large = p.sv.n_tris >= kLargeSceneTris;
-  if (count) fn = lds_scene ? pt_megakernel<true, false, true, MI_WAVES_LDS> : (large ? pt_megakernel<false, false, true, MI_WAVES_HBM_LARGE> : pt_megakernel<false, false, true, MI_WAVES_HBM>);
-  else if (lds_scene) fn = list ? pt_megakernel<true, true, false, MI_WAVES_LDS> : pt_megakernel<true, false, false, MI_WAVES_LDS>;
-  else if (large) fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM_LARGE> : pt_megakernel<false, false, false, MI_WAVES_HBM_LARGE>;
-  else fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM> : pt_megakernel<false, false, false, MI_WAVES_HBM>;
+  const bool large = p.wide_nodes != 0u;
+  if (count) fn = lds_scene ? pt_megakernel<true, false, true, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, false, true, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, false, true, MI_WAVES_HBM, 1>);
+  else if (lds_scene) fn = list ? pt_megakernel<true, true, false, MI_WAVES_LDS, 0> : pt_megakernel<true, false, false, MI_WAVES_LDS, 0>;
+  else if (large) fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, false, false, MI_WAVES_HBM_LARGE, 2>;
+  else fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM, 1> : pt_megakernel<false, false, false, MI_WAVES_HBM, 1>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(kBlock), lds, stream, p);
@@ -492,16 +494,20 @@ hipError_t launch_finalize(const double* partial, float* rgbn, uint32_t width, u
   return hipGetLastError();
 }
 
-hipError_t launch_intersect(const SceneView& sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* origins, const float* dirs,
+hipError_t launch_intersect(const SceneView& sv, bool wide, uint32_t stack_entries, uint32_t n, const mi_surface_point* origins, const float* dirs,
                             mi_surface_point* out_hits, float* out_t, uint32_t* out_prim, hipStream_t stream) {
-  hipLaunchKernelGGL(k_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, stack_entries, n,
+  if (wide) hipLaunchKernelGGL(k_intersect<2>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, stack_entries, n,
+                               origins, dirs, out_hits, out_t, out_prim);
+  else hipLaunchKernelGGL(k_intersect<1>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, stack_entries, n,
                      origins, dirs, out_hits, out_t, out_prim);
   return hipGetLastError();
 }
 
-hipError_t launch_occluded(const SceneView& sv, uint32_t stack_entries, uint32_t n, const mi_surface_point* a, const mi_surface_point* b,
+hipError_t launch_occluded(const SceneView& sv, bool wide, uint32_t stack_entries, uint32_t n, const mi_surface_point* a, const mi_surface_point* b,
                            float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_occluded, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, stack_entries, n, a, b,
+  if (wide) hipLaunchKernelGGL(k_occluded<2>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, stack_entries, n, a, b,
+                               out);
+  else hipLaunchKernelGGL(k_occluded<1>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, stack_entries, n, a, b,
                      out);
   return hipGetLastError();
 }

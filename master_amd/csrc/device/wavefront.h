@@ -6,7 +6,7 @@
 #include "layout.h"
 
 #ifndef MI_WF_QUANT
-#define MI_WF_QUANT 1  // traversal kernels walk the 32-byte quantised nodes
+#define MI_WF_QUANT 1  // traversal kernels: 1 = 32-byte quantised binary nodes, 2 = 64-byte wide nodes
 #endif
 
 namespace mi {

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock, 8) void wf_extend(const RenderParams p, con
     if (active) {
       const float4 d = w.ray_d[slot];
       Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-      traverse<false, COUNT, MI_WF_QUANT != 0>(p.sv.blob, p.sv, stack, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 0xFFFFFFFFu, h, &vis);
+      traverse<false, COUNT, MI_WF_QUANT>(p.sv.blob, p.sv, stack, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 0xFFFFFFFFu, h, &vis);
       w.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.id == 0xFFFFFFFFu ? 0xFFFFFFFFu : h.pos));
     }
   }
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kBlock, 8) void wf_shadow(const RenderParams p, con
       const float4 o = w.sh_o[slot], d = w.sh_d[slot];
       const f3 nee = F3(o.w, d.w, w.sh_z[slot]);
       Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
-      traverse<true, COUNT, MI_WF_QUANT != 0>(p.sv.blob, p.sv, stack, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 1u << MI_ENTITY_MESH, sh, &vis);
+      traverse<true, COUNT, MI_WF_QUANT>(p.sv.blob, p.sv, stack, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 1u << MI_ENTITY_MESH, sh, &vis);
       const float4 c = w.st_c[slot];
       const f3 r = F3(c.x, c.y, c.z) + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);
       w.st_c[slot] = make_float4(r.x, r.y, r.z, c.w);

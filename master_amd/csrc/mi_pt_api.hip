@@ -29,6 +29,9 @@ struct mi_pt_handle {
   mi_pt_params params{};
   float4* blob = nullptr;
   uint4* qnodes = nullptr;
+  uint4* qnodes4 = nullptr;
+  bool wide_nodes = false;         // HBM-resident kernels walk the wide nodes (scenes of >= 100 000 triangles; MI_PT_WIDE_NODES=0/1 overrides)
+  uint32_t stack_entries_hbm = 0;  // LDS rows of the traversal stack for kernels that read the scene from HBM (wide walk)
   mi::SceneView sv{};
   uint32_t* d_sorted_tri = nullptr;
   uint64_t* d_morton = nullptr;
@@ -115,7 +118,8 @@ int fill_camera(const mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint3
 
 void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   p.sv = h->sv;
-  p.stack_entries = h->info.stack_entries;
+  p.wide_nodes = h->wide_nodes ? 1u : 0u;
+  p.stack_entries = (use_lds_scene(h) && h->kernel_choice != MI_PT_KERNEL_WAVEFRONT) ? h->info.stack_entries : h->stack_entries_hbm;
   const uint64_t mp = h->params.max_path;
   p.max_path = mp >= 0x03FFFFFFull ? 0xFFFFFFFFu : uint32_t(mp);  // the kernel's path_size field has 26 bits: >= 2^26 - 1 edges = unlimited
   p.min_subpath = h->params.min_subpath;
@@ -251,17 +255,26 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
       h->sv.grid_lo[a] = h->info.scene_lo[a] - 2.0f / inv_step;
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->qnodes), size_t(n_nodes ? n_nodes : 1) * 32));
-    HIP_TRY(mi::quantize_nodes(n_nodes, reinterpret_cast<const mi_bvh_node*>(h->blob + sv.off_nodes), h->qnodes, h->sv.grid_lo, h->sv.grid_inv_step, h->stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->qnodes4), size_t(n_nodes ? n_nodes : 1) * 64));
+    HIP_TRY(mi::quantize_nodes(n_nodes, reinterpret_cast<const mi_bvh_node*>(h->blob + sv.off_nodes), h->qnodes, h->qnodes4, h->sv.grid_lo, h->sv.grid_inv_step, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->sv.qnodes = h->qnodes;
+    h->sv.qnodes = h->qnodes; h->sv.qnodes4 = h->qnodes4;
     // a root-to-leaf path of `depth` nodes has depth - 1 internal nodes, each of which can leave at most one
     // far child pending: that is the stack's capacity (rounded up to 4; LDS per workgroup = 1 KB per entry)
     uint32_t need = (depth > 1 ? depth - 1u : 1u);
     need = (need + 3u) / 4u * 4u;
     // LDS part of the stack: at most 12 entries (12 KB per workgroup); deeper levels spill to private memory
     uint32_t se = need < 12u ? need : 12u;
-    if (need > se + 64u) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack (12 LDS + 64 spill entries)");
+    // the wide walk of the HBM-resident kernels leaves up to three children pending per two binary levels
+    uint32_t need4 = 3u * ((depth > 1 ? depth - 1u : 1u) + 1u) / 2u;
+    need4 = (need4 + 3u) / 4u * 4u;
+    if (need4 < need) need4 = need;
+    const uint32_t se4 = need4 < 12u ? need4 : 12u;
+    if (need4 > se4 + 128u) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack (12 LDS + 128 spill entries)");
     h->info.stack_entries = se;
+    h->stack_entries_hbm = se4;
+    h->wide_nodes = nt >= 100000u;
+    if (const char* e = std::getenv("MI_PT_WIDE_NODES")) h->wide_nodes = std::atoi(e) != 0;
   }
   h->lds_fits = size_t(sv.blob_f4 + sv.n_nodes + sv.n_tris) * 16 <= kLdsSceneLimit;  // the LDS copy pads nodes and shading records by one float4
   guard.h = nullptr;
@@ -274,6 +287,7 @@ void mi_pt_destroy(mi_pt_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->blob) hipFree(h->blob);
   if (h->qnodes) hipFree(h->qnodes);
+  if (h->qnodes4) hipFree(h->qnodes4);
   if (h->d_sorted_tri) hipFree(h->d_sorted_tri);
   if (h->d_morton) hipFree(h->d_morton);
   if (h->partial) hipFree(h->partial);
@@ -433,7 +447,7 @@ int mi_pt_intersect(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_h), size_t(n) * sizeof(mi_surface_point))); tmp.p[2] = d_h;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_t), size_t(n) * 4)); tmp.p[3] = d_t;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_p), size_t(n) * 4)); tmp.p[4] = d_p;
-  HIP_TRY(mi::launch_intersect(h->sv, h->info.stack_entries, n, d_o, d_d, d_h, d_t, d_p, h->stream));
+  HIP_TRY(mi::launch_intersect(h->sv, h->wide_nodes, h->stack_entries_hbm, n, d_o, d_d, d_h, d_t, d_p, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (out_hits) HIP_TRY(hipMemcpy(out_hits, d_h, size_t(n) * sizeof(mi_surface_point), hipMemcpyDeviceToHost));
   if (out_t) HIP_TRY(hipMemcpy(out_t, d_t, size_t(n) * 4, hipMemcpyDeviceToHost));
@@ -450,7 +464,7 @@ int mi_pt_occluded(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins,
   int rc = upload(&d_a, origins, size_t(n) * sizeof(mi_surface_point)); tmp.p[0] = d_a; if (rc) return rc;
   rc = upload(&d_b, targets, size_t(n) * sizeof(mi_surface_point)); tmp.p[1] = d_b; if (rc) return rc;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_o), size_t(n) * 4)); tmp.p[2] = d_o;
-  HIP_TRY(mi::launch_occluded(h->sv, h->info.stack_entries, n, d_a, d_b, d_o, h->stream));
+  HIP_TRY(mi::launch_occluded(h->sv, h->wide_nodes, h->stack_entries_hbm, n, d_a, d_b, d_o, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_visibility, d_o, size_t(n) * 4, hipMemcpyDeviceToHost));
   return MI_OK;

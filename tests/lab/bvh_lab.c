@@ -66,16 +66,77 @@ static int32_t sah_build(orc_scene* s, prim_t* p, int n, float* tmp, float out_l
   if (b >= 0) s->nodes[b].parent = me;
   return (int32_t)me;
 }
+/* ---- early split clipping: a triangle whose box is much larger than the triangle becomes 2..16 references with the boxes
+ * of its pieces (bisect the piece's box along its longest axis, clip the polygon) ---- */
+typedef struct { float v[12][3]; int n; } poly_t;
+static void poly_bounds(const poly_t* q, float lo[3], float hi[3]) {
+  for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+  for (int i = 0; i < q->n; ++i) for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], q->v[i][a]); hi[a] = fmaxf(hi[a], q->v[i][a]); }
+}
+static void poly_clip(const poly_t* in, int axis, float c, int keep_less, poly_t* out) {
+  out->n = 0;
+  for (int i = 0; i < in->n; ++i) {
+    const float* a = in->v[i]; const float* b = in->v[(i + 1) % in->n];
+    int ia = keep_less ? a[axis] <= c : a[axis] >= c, ib = keep_less ? b[axis] <= c : b[axis] >= c;
+    if (ia) { memcpy(out->v[out->n++], a, 12); }
+    if (ia != ib) {
+      float t = (c - a[axis]) / (b[axis] - a[axis]);
+      float* o = out->v[out->n++];
+      for (int k = 0; k < 3; ++k) o[k] = a[k] + (b[k] - a[k]) * t;
+      o[axis] = c;
+    }
+  }
+}
+static int split_rec(const poly_t* q, int levels, prim_t* out, int32_t leaf) {
+  float lo[3], hi[3]; poly_bounds(q, lo, hi);
+  if (levels == 0 || q->n < 3) {
+    if (q->n < 1) return 0;
+    for (int a = 0; a < 3; ++a) { out->lo[a] = lo[a]; out->hi[a] = hi[a]; }
+    pad_box(out->lo, out->hi);
+    for (int a = 0; a < 3; ++a) out->c[a] = 0.5f * (out->lo[a] + out->hi[a]);
+    out->leaf = leaf;
+    return 1;
+  }
+  int ax = 0; float e = hi[0] - lo[0];
+  for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > e) { e = hi[a] - lo[a]; ax = a; }
+  float c = 0.5f * (lo[ax] + hi[ax]);
+  poly_t l, r; poly_clip(q, ax, c, 1, &l); poly_clip(q, ax, c, 0, &r);
+  int n = split_rec(&l, levels - 1, out, leaf);
+  return n + split_rec(&r, levels - 1, out + n, leaf);
+}
+static int g_split_levels_max = 0;
+ORC_API void lab_set_split(int max_levels) { g_split_levels_max = max_levels; }
+
 ORC_API void lab_build_sah(orc_scene* s) {
   int n = (int)s->d.n_triangles;
   if (n < 2) return;
-  prim_t* p = (prim_t*)malloc(sizeof(prim_t) * (size_t)n);
-  float* tmp = (float*)malloc(sizeof(float) * (size_t)n);
+  prim_t* p = (prim_t*)malloc(sizeof(prim_t) * (size_t)n * 16);
+  int np = 0;
   for (int i = 0; i < n; ++i) {
-    tri_bounds(s, s->sorted_tri[i], p[i].lo, p[i].hi); pad_box(p[i].lo, p[i].hi);
-    for (int a = 0; a < 3; ++a) p[i].c[a] = 0.5f * (p[i].lo[a] + p[i].hi[a]);
-    p[i].leaf = ~i;
+    float lo[3], hi[3]; tri_bounds(s, s->sorted_tri[i], lo, hi);
+    int levels = 0;
+    if (g_split_levels_max > 0) {
+      const tri_t* t = &s->tris_sorted[i];
+      float at = sqrtf(vdot(t->ng, t->ng));                 /* 2 x triangle area */
+      float ab = 2.0f * box_area(lo, hi);                   /* box surface area */
+      float r = ab / (2.0f * at + 1e-30f);
+      while (levels < g_split_levels_max && r > 4.0f) { ++levels; r *= 0.5f; }
+    }
+    if (levels == 0) {
+      memcpy(p[np].lo, lo, 12); memcpy(p[np].hi, hi, 12); pad_box(p[np].lo, p[np].hi);
+      for (int a = 0; a < 3; ++a) p[np].c[a] = 0.5f * (p[np].lo[a] + p[np].hi[a]);
+      p[np].leaf = ~i; ++np;
+    } else {
+      poly_t q; q.n = 3;
+      const uint32_t* idx = s->indices + 3 * (size_t)s->sorted_tri[i];
+      for (int k = 0; k < 3; ++k) memcpy(q.v[k], s->positions + 3 * (size_t)idx[k], 12);
+      np += split_rec(&q, levels, p + np, ~i);
+    }
   }
+  fprintf(stderr, "lab: %d triangles -> %d references\n", n, np);
+  free(s->nodes); s->n_nodes = (uint32_t)(np - 1); s->nodes = (bnode_t*)calloc(s->n_nodes, sizeof(bnode_t));
+  n = np;
+  float* tmp = (float*)malloc(sizeof(float) * (size_t)n);
   g_next = 0; float lo[3], hi[3];
   sah_build(s, p, n, tmp, lo, hi);
   s->nodes[0].parent = UINT32_MAX;

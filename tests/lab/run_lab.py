@@ -37,10 +37,11 @@ def main():
         rng = np.random.default_rng(1); n = 6000
         W, H = 320, 180
         xy = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], 1).astype(np.uint32); si = rng.integers(0, 64, n).astype(np.uint64)
-        for variant in ("lbvh", "ploc", "ploc+rot", "lbvh+rot", "sah", "sah+rot"):
+        for variant in os.environ.get("LAB_VARIANTS", "lbvh,ploc,ploc+rot,lbvh+rot,sah,sah+rot").split(","):
             os.environ["MI_PT_BVH"] = "lbvh" if variant.startswith("lbvh") else "ploc"
             o = oracle.Oracle(s)
             if variant.startswith("sah"):
+                L.lab_set_split(int(variant[3]) if len(variant) > 3 and variant[3].isdigit() else 0)
                 L.lab_build_sah(o._h)
             rot = L.lab_rotate(o._h, 8) if variant.endswith("+rot") else 0
             cnt = (C.c_uint64 * 4)()

@@ -87,6 +87,29 @@ def test_intersect_and_occluded_bit_exact(builder, name):
     assert np.array_equal(gp[:nb], bp) and np.array_equal(gt[:nb], bt)
 
 
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxSpecular", "MirrorBalls", "MetalRings", "LivingRoomLit", "soup20000", "single", "TestCase27"])
+def test_wide_node_walk_is_exact(monkeypatch, name):
+    """The HBM-resident kernels of large scenes walk 64-byte wide nodes (four grandchildren per record).  Forced on for
+    small scenes here: closest hits, visibility and whole paths must not change (the hit is the (t, id) minimum)."""
+    s = get_scene(name)
+    monkeypatch.setenv("MI_PT_WIDE_NODES", "0"); binary = ma.PathTracing(s)
+    monkeypatch.setenv("MI_PT_WIDE_NODES", "1"); pt = ma.PathTracing(s)
+    orc = oracle.Oracle(s)
+    pt.set_kernel(ma.KERNEL_MEGA_GLOBAL); binary.set_kernel(ma.KERNEL_MEGA_GLOBAL)
+    o, d = rays(s, 100000, 7)
+    gh, gt, gp = pt.intersect(o, d); oh, ot, op = orc.intersect(o, d)
+    assert np.array_equal(gp, op) and np.array_equal(gt, ot) and gh.tobytes() == oh.tobytes()
+    tg, _ = rays(s, 100000, 8)
+    assert np.array_equal(pt.occluded(o, tg), orc.occluded(o, tg))
+    # whole paths against the binary walk on the same device (same pow on both sides: exact also for Phong scenes)
+    xy, si = grid_paths(48, 40, 6)
+    g, gc = pt.trace_paths(48, 40, xy, si, seed=7); r, rc = binary.trace_paths(48, 40, xy, si, seed=7)
+    assert np.array_equal(gc, rc)
+    assert ((g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))).all()
+    img = pt.render_rgbn(64, 48, spp=8, seed=5); ref = binary.render_rgbn(64, 48, spp=8, seed=5)
+    assert np.array_equal(img, ref)
+
+
 def test_intersect_edge_cases(cornell):
     pt, orc = ma.PathTracing(cornell), oracle.Oracle(cornell)
     o, d = rays(cornell, 64, 3)

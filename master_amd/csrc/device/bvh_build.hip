@@ -452,38 +452,46 @@ __global__ void k_quantize(uint32_t n_nodes, const mi_bvh_node* __restrict__ nod
   qnodes[2 * size_t(i) + 1] = b;
 }
 
-// wide node of every even-depth BVH2 node: its children, internal ones replaced by their own children
-__global__ void k_collapse4(uint32_t n_nodes, const mi_bvh_node* __restrict__ nodes, uint4* __restrict__ q4, float lx, float ly, float lz,
-                            float ix, float iy, float iz) {
+// wide nodes: one record per even-depth BVH2 node = its children, internal ones replaced by their own children.
+// k_even_depth flags those nodes; an exclusive scan of the flags numbers the records contiguously (pre-order of the BVH2
+// numbering is kept), so that every fetched cache line holds two live records.
+__global__ void k_even_depth(uint32_t n_nodes, const mi_bvh_node* __restrict__ nodes, uint32_t* __restrict__ flag) {
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= n_nodes) return;
   uint32_t depth = 0;
   for (uint32_t p = nodes[x].parent; p != 0xFFFFFFFFu; p = nodes[p].parent) ++depth;
+  flag[x] = (depth & 1u) ^ 1u;
+}
+__global__ void k_collapse4(uint32_t n_nodes, const mi_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ flag_scan, uint4* __restrict__ q4,
+                            float lx, float ly, float lz, float ix, float iy, float iz) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n_nodes) return;
+  const uint32_t me = flag_scan[x];
+  const bool even = (x + 1 < n_nodes ? flag_scan[x + 1] : flag_scan[n_nodes]) != me;  // exclusive scan: the flag is the difference
+  if (!even) return;
   uint4 out[4];
   for (int k = 0; k < 4; ++k) out[k] = make_uint4(0xFFFFu | (0xFFFFu << 16), 0xFFFFu, 0u, 0x7FFFFFFFu);  // empty: link kEmptyLink
-  if ((depth & 1u) == 0u) {
-    const mi_bvh_node n = nodes[x];
-    int k = 0;
-    auto put = [&](const float* lo, const float* hi, int link) {
-      uint4 a;
-      a.x = q_lo(lo[0], lx, ix) | (q_lo(lo[1], ly, iy) << 16);
-      a.y = q_lo(lo[2], lz, iz) | (q_hi(hi[0], lx, ix) << 16);
-      a.z = q_hi(hi[1], ly, iy) | (q_hi(hi[2], lz, iz) << 16);
-      a.w = uint32_t(link);
-      out[k++] = a;
-    };
-    const int links[2] = {n.link0, n.link1};
-    for (int c = 0; c < 2; ++c) {
-      if (links[c] < 0) {
-        if (c == 0) put(n.lo0, n.hi0, links[c]); else put(n.lo1, n.hi1, links[c]);
-      } else {
-        const mi_bvh_node m = nodes[links[c]];
-        put(m.lo0, m.hi0, m.link0);
-        put(m.lo1, m.hi1, m.link1);
-      }
+  const mi_bvh_node n = nodes[x];
+  int k = 0;
+  auto put = [&](const float* lo, const float* hi, int link) {
+    uint4 a;
+    a.x = q_lo(lo[0], lx, ix) | (q_lo(lo[1], ly, iy) << 16);
+    a.y = q_lo(lo[2], lz, iz) | (q_hi(hi[0], lx, ix) << 16);
+    a.z = q_hi(hi[1], ly, iy) | (q_hi(hi[2], lz, iz) << 16);
+    a.w = link >= 0 ? flag_scan[link] : uint32_t(link);  // internal grandchildren are even-depth nodes: their record number
+    out[k++] = a;
+  };
+  const int links[2] = {n.link0, n.link1};
+  for (int c = 0; c < 2; ++c) {
+    if (links[c] < 0) {
+      if (c == 0) put(n.lo0, n.hi0, links[c]); else put(n.lo1, n.hi1, links[c]);
+    } else {
+      const mi_bvh_node m = nodes[links[c]];
+      put(m.lo0, m.hi0, m.link0);
+      put(m.lo1, m.hi1, m.link1);
     }
   }
-  for (int k = 0; k < 4; ++k) q4[4 * size_t(x) + k] = out[k];
+  for (int k2 = 0; k2 < 4; ++k2) q4[4 * size_t(me) + k2] = out[k2];
 }
 
 #define BUILD_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
@@ -596,8 +604,17 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
 hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, uint4* qnodes4, const float lo[3], const float inv_step[3],
                           hipStream_t stream) {
   if (n_nodes == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_collapse4, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, qnodes4, lo[0], lo[1], lo[2], inv_step[0],
+  uint32_t* flag = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&flag), sizeof(uint32_t) * (size_t(n_nodes) + 1));
+  if (e != hipSuccess) return e;
+  hipMemsetAsync(flag + n_nodes, 0, sizeof(uint32_t), stream);
+  hipLaunchKernelGGL(k_even_depth, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, flag);
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, flag, n_nodes + 1);
+  hipLaunchKernelGGL(k_collapse4, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, flag, qnodes4, lo[0], lo[1], lo[2], inv_step[0],
                      inv_step[1], inv_step[2]);
+  e = hipStreamSynchronize(stream);
+  hipFree(flag);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_quantize, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, qnodes, lo[0], lo[1], lo[2], inv_step[0],
                      inv_step[1], inv_step[2]);
   return hipGetLastError();

@@ -19,7 +19,8 @@ def parse(path, want):
         if not line.startswith(" "):
             cur = line.strip()
             continue
-        if want in cur and "true>" not in cur.replace(" ", "").split("megakernel")[-1][-6:]:  # skip the COUNT variant
+        args = cur.replace(" ", "").split("<")[-1].rstrip(">").split(",") if "<" in cur else []
+        if want in cur and not (len(args) >= 3 and args[2] == "true"):  # skip the instrumented (COUNT) variant
             k, v = line.split()
             out[k] = float(v)
     return out

@@ -452,106 +452,4 @@ MI_DEV f3 connect_prepare(const float4* __restrict__ sb, const SceneView& sv, Rn
   return r / wInv;
 }
 
-// Ray / triangle test with the ray kind chosen at run time (same arithmetic as tri_test<>).
-MI_DEV bool tri_test_rt(bool any, const float4* __restrict__ tris, uint32_t pos, f3 org, f3 dir, uint32_t ray_mask, Hit& h) {
-  const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
-  const uint32_t mask = __float_as_uint(c.z);
-  if (!(mask & ray_mask)) return false;
-  const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
-  const uint32_t id = __float_as_uint(c.y);
-  const f3 ng = cross(e2, e1);
-  const f3 C = v0 - org;
-  const f3 R = cross(C, dir);
-  const float den = dot(ng, dir);
-  const float absden = fabsf(den);
-  const float sgn = den < 0.0f ? -1.0f : 1.0f;
-  const float U = dot(R, e2) * sgn;
-  const float V = dot(R, e1) * sgn;
-  if (den == 0.0f) return false;
-  if (!(U >= 0.0f) || !(V >= 0.0f) || !(U + V <= absden)) return false;
-  const float T = dot(ng, C) * sgn;
-  if (!(absden * 0.0f < T)) return false;
-  const float t = T / absden;
-  if (any) {
-    if (t <= h.t) { h.id = id; return true; }
-    return false;
-  }
-  if (t < h.t || (t == h.t && id < h.id)) {
-    h.t = t; h.u = U / absden; h.v = V / absden; h.id = id; h.pos = pos;
-    return true;
-  }
-  return false;
-}
-
-// One traversal loop for up to two rays of a lane: first the pending shadow ray of the previous
-// vertex (any-hit, t in (0,1], surface meshes only: Scene.cpp:165-179), then the closest-hit ray
-// (Scene.cpp:190-198).  Fusing them keeps lanes busy: the loop runs max(Ns + Nc) trips over the
-// wave instead of max(Ns) + max(Nc); lanes without a shadow ray start on their closest-hit ray.
-// Explicit while-while form: an inner loop over internal nodes, then one leaf test.
-constexpr int kNodeDone = int(0x80000000u);
-
-template <bool COUNT>
-MI_DEV void traverse_fused(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, bool has_shadow,
-                           const ShadowRay& sray, f3 org, f3 dir, Hit& h, float& visibility, Visits* vis_c, Visits* vis_s) {
-  const float4* nodes = sb + sv.off_nodes;
-  const float4* tris = sb + sv.off_tris;
-  const int root = sv.n_nodes ? 0 : ~0;
-  bool any = has_shadow;
-  f3 o = any ? sray.org : org, d = any ? sray.dir : dir;
-  Hit cur;
-  cur.t = any ? 1.0f : __builtin_inff(); cur.u = cur.v = 0.0f; cur.id = 0xFFFFFFFFu; cur.pos = 0;
-  uint32_t mask = any ? (1u << MI_ENTITY_MESH) : 0xFFFFFFFFu;
-  RayBox rb = make_raybox(o, d);
-  int sp = 0;
-  int node = root;
-  visibility = 1.0f;
-  for (;;) {
-    while (node >= 0) {
-      const float4 n0 = nodes[4 * node], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
-      if (COUNT) { if (any) ++vis_s->nodes; else ++vis_c->nodes; }
-      float tn0, tn1;
-      const bool h0 = box_test(xyz(n0), xyz(n1), rb, cur.t, tn0);
-      const bool h1 = box_test(xyz(n2), xyz(n3), rb, cur.t, tn1);
-      const int l0 = __float_as_int(n0.w), l1 = __float_as_int(n1.w);
-      if (h0 && h1) {
-        const bool sw = tn1 < tn0;
-        stack.push(sp, uint32_t(sw ? l0 : l1));
-        ++sp;
-        node = sw ? l1 : l0;
-      } else if (h0 || h1) {
-        node = h0 ? l0 : l1;
-      } else if (sp != 0) {
-        --sp;
-        node = int(stack.pop(sp));
-      } else {
-        node = kNodeDone;
-      }
-    }
-    if (node != kNodeDone) {
-      if (COUNT) { if (any) ++vis_s->tris; else ++vis_c->tris; }
-      const bool hit = tri_test_rt(any, tris, uint32_t(~node), o, d, mask, cur);
-      if (any && hit) {
-        node = kNodeDone;
-      } else if (sp != 0) {
-        --sp;
-        node = int(stack.pop(sp));
-      } else {
-        node = kNodeDone;
-      }
-    }
-    if (node == kNodeDone) {
-      if (!any) break;
-      visibility = cur.id != 0xFFFFFFFFu ? 0.f : 1.f;
-      any = false;
-      o = org; d = dir;
-      cur.t = __builtin_inff(); cur.id = 0xFFFFFFFFu;
-      mask = 0xFFFFFFFFu;
-      rb = make_raybox(o, d);
-      sp = 0;
-      node = root;
-    }
-  }
-  h = cur;
-}
-
 }  // namespace mi

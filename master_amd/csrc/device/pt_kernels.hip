@@ -41,12 +41,8 @@ MI_DEV uint32_t wave_sum(uint32_t v) {
 
 constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums, counts, 8 instrumentation words
 
-#ifndef MI_FUSED_TRAVERSAL
-#define MI_FUSED_TRAVERSAL 0  // 1: shadow ray of vertex k rides in the closest-hit loop of trip k+1 (measured slower: profiles/r01/ab_fused.txt)
-#endif
-#ifndef MI_SHADOW_AFTER_SAMPLE
-#define MI_SHADOW_AFTER_SAMPLE 0  // 0: shadow ray traversed inside the NEE step, before the BSDF sample (measured +2 %)
-#endif
+// Measured and removed (profiles/r01): the shadow ray of vertex k riding in the closest-hit loop of trip k+1 (-18 %, ab_fused.txt);
+// the shadow ray traversed after the BSDF sample instead of inside the NEE step (-7 %, ab_launch_bounds.txt).
 // Second __launch_bounds__ argument = minimum waves per SIMD the register budget must allow.  Measured on
 // CornellBoxDiffuse (LDS-resident scene): 3 waves 6.1, 4 waves 7.1, 5 waves 7.7, 6 waves 8.1, 8 waves 6.7 Gsamples/s
 // (profiles/r01/ab_launch_bounds.txt); the 6-wave build spills 136 B/lane to scratch and still wins on latency hiding.
@@ -148,7 +144,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   uint32_t item_id = 0;
   uint32_t n_basic = 0, n_shadow = 0, n_err = 0, n_paths = 0;  // wave-uniform (ballot popcounts): live in SGPRs
   uint32_t path_basic = 0, path_shadow = 0;  // LIST mode per-path counts
-  bool pending = false;                      // a shadow ray of the previous vertex waits to be traversed
+  bool pending = false;                      // this vertex has a shadow ray to traverse (connect_prepare)
   ShadowRay sray; sray.org = F3(0, 0, 0); sray.dir = F3(0, 0, 1);
   f3 nee = F3(0, 0, 0);                      // its contribution if unoccluded (PT.cpp:117-119 without the visibility)
   Visits vis_c = {0u, 0u, nullptr}, vis_s = {0u, 0u, nullptr};  // instrumented variant only
@@ -218,23 +214,13 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
     if (alive) {
       // ---- Scene::intersect (Scene.cpp:182-203) ----
       Hit h;
-#if MI_FUSED_TRAVERSAL
-      // (+ the shadow ray of the previous vertex, Scene::occluded, in the same loop)
-      float visibility;
-      traverse_fused<COUNT>(sb, sv, stack, pending, sray, org, dir, h, visibility, &vis_c, &vis_s);
-      if (pending) radiance = radiance + nee * visibility;  // PT.cpp:41: radiance += _connect(...)
-      pending = false;
-#else
       h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
       const uint32_t steps0 = vis_c.nodes + vis_c.tris;
       traverse<false, COUNT, QN, NS>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
-#endif
       MI_STAMP(1);  // closest-hit traversal
       ++path_basic;
       if (COUNT && h.id != 0xFFFFFFFFu) ++n_hits;
-#if !MI_FUSED_TRAVERSAL
       if (COUNT) steps_mine_c = vis_c.nodes + vis_c.tris - steps0;
-#endif
 
       bool terminate = false, do_vertex = false;
       Surf sp;
@@ -300,7 +286,6 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         nee = connect_prepare(sb, sv, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
         if (pending) { t_shadow = true; ++path_shadow; }
         MI_STAMP(3);  // NEE set-up
-#if !MI_FUSED_TRAVERSAL && !MI_SHADOW_AFTER_SAMPLE
         // a contribution that is exactly zero (delta BSDF at x, black surface) cannot change the sum whatever the
         // visibility: the ray the reference would cast (and count, Scene.cpp:177) is counted but not traversed
         if (pending && !(nee.x != 0.0f || nee.y != 0.0f || nee.z != 0.0f)) pending = false;
@@ -312,7 +297,6 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
           radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
           pending = false;
         }
-#endif
         MI_STAMP(4);  // shadow traversal
         const f3 x_position = sp.position, x_gnormal = sp.gnormal;
         const BSample bs = bsdf_sample(mat, rng, sp, x_omega);
@@ -323,15 +307,6 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         dir = bs.omega;
         org = nudge(x_position, x_gnormal, dir);
         bounce = true;
-#if !MI_FUSED_TRAVERSAL && MI_SHADOW_AFTER_SAMPLE
-        // the shadow ray is traversed after the BSDF sample so that the surface frame and the material are dead by now
-        if (pending) {
-          Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
-          traverse<true, COUNT, QN, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
-          radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
-          pending = false;
-        }
-#endif
       }
 
       MI_STAMP(5);  // BSDF sample

@@ -864,6 +864,8 @@ static v3 trace_one(const orc_scene* s, const cam_ctx_t* c, uint32_t x, uint32_t
   return pt_trace_eye(s, &g, &c->cs, wd, cnt);
 }
 
+#include "bpt_oracle.inc" /* BPT restatement (next row of SURVEY 8(f)); shares every function above */
+
 /* ------------------------------------------------------------------ exported API */
 ORC_API orc_scene* orc_create(const mi_scene_desc* d, const mi_pt_params* p, int use_bvh) {
   orc_scene* s = (orc_scene*)calloc(1, sizeof *s);
@@ -895,6 +897,24 @@ ORC_API orc_scene* orc_create(const mi_scene_desc* d, const mi_pt_params* p, int
   for (uint32_t i = 0; i < d->n_lights; ++i) {
     s->light_weight[i] = light_area(&s->lights[i]) * l1norm(ld3(s->lights[i].exitance)) * total_inv;
     s->light_cdf[i + 1] = s->light_cdf[i] + s->light_weight[i];
+  }
+  if (!(s->d.bounding_sphere[3] > 0.0f)) { /* compute_bounding_sphere (loader.cpp:408-432): surface meshes only, before the light quads */
+    double c[3] = {0, 0, 0}; size_t nv = 0;
+    for (uint32_t m = 0; m < d->n_meshes; ++m) {
+      if ((s->mesh_material_id[m] & 3u) != MI_ENTITY_MESH) continue;
+      for (uint32_t t = s->mesh_tri_offset[m]; t < s->mesh_tri_offset[m + 1]; ++t)
+        for (int k = 0; k < 3; ++k) { const float* p = s->positions + 3 * (size_t)s->indices[3 * t + k]; c[0] += p[0]; c[1] += p[1]; c[2] += p[2]; ++nv; }
+    }
+    if (nv) {
+      float cx = (float)(c[0] / (double)nv), cy = (float)(c[1] / (double)nv), cz = (float)(c[2] / (double)nv), r2 = 0.0f;
+      for (uint32_t m = 0; m < d->n_meshes; ++m) {
+        if ((s->mesh_material_id[m] & 3u) != MI_ENTITY_MESH) continue;
+        for (uint32_t t = s->mesh_tri_offset[m]; t < s->mesh_tri_offset[m + 1]; ++t)
+          for (int k = 0; k < 3; ++k) { const float* p = s->positions + 3 * (size_t)s->indices[3 * t + k];
+            float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz, q = dx * dx + dy * dy + dz * dz; if (q > r2) r2 = q; }
+      }
+      s->d.bounding_sphere[0] = cx; s->d.bounding_sphere[1] = cy; s->d.bounding_sphere[2] = cz; s->d.bounding_sphere[3] = sqrtf(r2);
+    }
   }
   build_bvh(s);
   return s;

@@ -16,8 +16,8 @@ _lib = None
 
 
 def build():
-    src = os.path.join(ORACLE_DIR, "pt_oracle.c")
-    if not os.path.exists(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "mi_pt.h"))):
+    srcs = [os.path.join(ORACLE_DIR, "pt_oracle.c"), os.path.join(ORACLE_DIR, "bpt_oracle.inc"), os.path.join(ROOT, "include", "mi_pt.h")]
+    if not os.path.exists(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
     return ORACLE_LIB
 
@@ -39,6 +39,8 @@ def lib():
         L.orc_occluded.argtypes = [vp, u32, vp, vp, vp]
         L.orc_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp]
         L.orc_render.argtypes = [vp, u32, u32, u32, ma.Window, u32, u64, u64, vp, C.POINTER(ma.PtStats), C.c_int]
+        L.orc_bpt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp, vp]
+        L.orc_bpt_render.argtypes = [vp, u32, u32, u32, u32, u64, u64, vp, C.POINTER(ma.PtStats), C.c_int]
         L.orc_camera_setup.argtypes = [C.POINTER(ma.Camera), f32, C.POINTER(ma.CameraFrame)]
         L.orc_ray_direction.argtypes = [f32, f32, f32, f32, f32, C.POINTER(f32)]
         L.orc_pixel_position.argtypes = [C.POINTER(f32), f32, f32, f32, C.POINTER(f32)]
@@ -116,6 +118,24 @@ class Oracle:
         cnt = np.zeros((n, 2), np.uint32)
         lib().orc_trace_paths(self._h, camera_id, width, height, n, _ptr(pixel_xy), _ptr(sample_index), seed, _ptr(rad), _ptr(cnt))
         return rad, cnt
+
+    def bpt_trace_paths(self, width, height, pixel_xy, sample_index, seed=0, camera_id=0):
+        """BPT (BPT.cpp): per path the eye-image radiance, the float sum of its light-image splats, and (closest, shadow, splats) counts."""
+        pixel_xy = np.ascontiguousarray(pixel_xy, np.uint32).reshape(-1, 2)
+        sample_index = np.ascontiguousarray(sample_index, np.uint64)
+        n = len(pixel_xy)
+        rad = np.zeros((n, 3), np.float32); spl = np.zeros((n, 3), np.float32); cnt = np.zeros((n, 3), np.uint32)
+        lib().orc_bpt_trace_paths(self._h, camera_id, width, height, n, _ptr(pixel_xy), _ptr(sample_index), C.c_uint64(seed), _ptr(rad), _ptr(spl), _ptr(cnt))
+        return rad, spl, cnt
+
+    def bpt_render_rgbn(self, width, height, spp=1, seed=0, sample_offset=0, camera_id=0, threads=None):
+        out = np.zeros((height, width, 4), np.float32)
+        st = ma.PtStats()
+        rc = lib().orc_bpt_render(self._h, camera_id, width, height, spp, C.c_uint64(seed), C.c_uint64(sample_offset), _ptr(out), C.byref(st),
+                                  threads or (os.cpu_count() or 1))
+        assert rc == 0, rc
+        self.last_stats = st
+        return out
 
     def bvh_info(self):
         info = ma.BvhInfo()

@@ -1,0 +1,55 @@
+"""CPU tests of the BPT restatement (oracle/bpt_oracle.inc) — the checker for the next row of SURVEY.md 8(f).
+The reference has no executable BPT tests; its unit_test.py renders models/TestCase*.blend with BPT and compares the image
+average with a constant: those models are normalised by their author to an average of 1.  That, and agreement with the PT
+restatement (same expectation, different estimator), pin this oracle."""
+import numpy as np
+import pytest
+
+import master_amd as ma
+import oracle
+from conftest import load_scene
+
+
+def _mean(img):
+    return float((img[..., :3] / np.maximum(img[..., 3:], 1)).mean())
+
+
+@pytest.mark.parametrize("name,beta", [("TestCase0", 2.0), ("TestCase2", 1.0), ("TestCase9", 2.0), ("TestCase25", 0.0), ("TestCaseFurnace", 2.0),
+                                       ("TestCase10", 2.0), ("TestCase13", 1.0), ("TestCase18", 2.0), ("TestCase29", 2.0), ("TestCase33", 1.5)])
+def test_normalised_models_average_one(name, beta):
+    """Area lights (TestCase0/2/9/25, furnace) and sun lights (TestCase10/13/18/29/33: PT cannot light these at all) — the
+    bidirectional estimator with every beta variant of Beta.hpp averages 1 over the image."""
+    s = load_scene(name)
+    img = oracle.Oracle(s, beta=beta).bpt_render_rgbn(48, 48, spp=48, seed=3, threads=8)
+    assert np.all(img[..., 3] == 48) and np.isfinite(img).all()
+    assert abs(_mean(img) - 1.0) < 0.03, _mean(img)
+
+
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxSpecular", "MirrorAndAreaLight"])
+def test_bpt_and_pt_agree(name):
+    s = load_scene(name)
+    o = oracle.Oracle(s, beta=2.0)
+    b = o.bpt_render_rgbn(48, 48, spp=96, seed=1, threads=8); p = o.render_rgbn(48, 48, spp=96, seed=2, threads=8)
+    assert abs(_mean(b) - _mean(p)) / _mean(p) < 0.03
+
+
+def test_paths_are_deterministic_and_splats_stay_in_the_image(cornell):
+    o = oracle.Oracle(cornell, beta=2.0)
+    rng = np.random.default_rng(5); n = 4000
+    xy = np.stack([rng.integers(0, 64, n), rng.integers(0, 48, n)], 1).astype(np.uint32); si = rng.integers(0, 32, n).astype(np.uint64)
+    r1, s1, c1 = o.bpt_trace_paths(64, 48, xy, si, seed=7); r2, s2, c2 = o.bpt_trace_paths(64, 48, xy, si, seed=7)
+    assert np.array_equal(r1, r2) and np.array_equal(s1, s2) and np.array_equal(c1, c2)
+    assert np.isfinite(r1).all() and np.isfinite(s1).all()
+    # the light sub-path is connected to the camera at most once per vertex: splats <= shadow rays; paths killed by the first roulette cast nothing
+    assert (c1[:, 2] <= c1[:, 1]).all()
+    dead = c1[:, 0] == 0
+    assert 0.05 < dead.mean() < 0.15 and not r1[dead].any() and not c1[dead].any()
+    img = o.bpt_render_rgbn(64, 48, spp=4, seed=7, threads=4)
+    assert np.all(img[..., 3] == 4)
+
+
+def test_sun_lights_are_invisible_to_pt_but_not_to_bpt():
+    s = load_scene("TestCase12")
+    o = oracle.Oracle(s, beta=2.0)
+    assert _mean(o.render_rgbn(32, 32, spp=32, seed=1, threads=8)) < 0.1
+    assert abs(_mean(o.bpt_render_rgbn(32, 32, spp=64, seed=1, threads=8)) - 1.0) < 0.08

@@ -256,6 +256,21 @@ typedef struct mi_bvh_info {
   uint32_t build_rounds; /* PLOC merge rounds                                           */
 } mi_bvh_info;
 
+/* ------------------------------------------------------------------------------------------
+ * Bidirectional path tracing (BPTBase<Beta>, BPT.cpp:13-337; created by make_bpt_technique, make_technique.cpp:112-130)
+ * on the same handle: roulette and beta come from mi_pt_params (beta 0, 1, 2 = FixedBeta<0|1|2>, anything else VariableBeta,
+ * Beta.hpp); max_path and lights are not used by BPT.  SURVEY.md 8(f) rank 4 — first device version.
+ *
+ * mi_bpt_render: `spp` frames of the whole image.  Per frame every pixel traces one light sub-path and one eye sub-path
+ * (BPT.cpp:13-101); connections to the camera are splatted into the frame's light image (Technique.cpp:276-306) and the sum
+ * light + eye of a pixel passes the finite filter as one sample (Technique.cpp:194-244).  rgbn_sum as in mi_pt_render.
+ * mi_bpt_trace_paths: parity hook — per listed (pixel, sample) the eye-image radiance, the sum of its light-image splats and
+ * the counts (closest-hit rays, shadow rays, splats). */
+int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed,
+                  uint64_t sample_offset, float* rgbn_sum, mi_pt_stats* stats);
+int mi_bpt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_xy,
+                       const uint64_t* sample_index, uint64_t seed, float* out_radiance, float* out_splat_sum, uint32_t* out_counts3);
+
 int mi_pt_bvh_info(mi_pt_handle* h, mi_bvh_info* out);
 /* The device scene blob as float4 records (layout: master_amd/csrc/device/layout.h): sections in
  * order nodes | triangles | shading | materials | lights | light cdf.  offsets_f4[7] receives the

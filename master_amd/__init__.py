@@ -111,6 +111,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version",
     "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
+    "mi_bpt_render", "mi_bpt_trace_paths",
     "mi_pt_bvh_download", "mi_pt_blob_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
     "mi_scene_load", "mi_scene_save", "mi_scene_from_desc", "mi_scene_get_desc", "mi_scene_material_name", "mi_scene_mesh_name",
     "mi_scene_free", "mi_exr_save_rgbn", "mi_exr_load_rgbn", "mi_free", "mi_rms_abs_errors",
@@ -140,6 +141,8 @@ def lib():
     L.mi_pt_intersect.argtypes = [vp, u32, vp, vp, vp, vp, vp]
     L.mi_pt_occluded.argtypes = [vp, u32, vp, vp, vp]
     L.mi_pt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp]
+    L.mi_bpt_render.argtypes = [vp, u32, u32, u32, u32, u64, u64, vp, C.POINTER(PtStats)]
+    L.mi_bpt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp, vp]
     L.mi_pt_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]
     L.mi_pt_bvh_download.argtypes = [vp, vp, vp, vp]
     L.mi_pt_blob_download.argtypes = [vp, C.POINTER(u32), vp, C.c_size_t]
@@ -449,6 +452,23 @@ class PathTracing:
         cnt = np.zeros((n, 2), np.uint32)
         _check(lib().mi_pt_trace_paths(self._h, camera_id, width, height, n, _ptr(pixel_xy), _ptr(sample_index), seed, _ptr(rad), _ptr(cnt)))
         return rad, cnt
+
+    def bpt_trace_paths(self, width, height, pixel_xy, sample_index, seed=0, camera_id=0):
+        """BPT (BPT.cpp) per path: eye-image radiance, sum of light-image splats, (closest rays, shadow rays, splats)."""
+        pixel_xy = np.ascontiguousarray(pixel_xy, np.uint32).reshape(-1, 2)
+        sample_index = np.ascontiguousarray(sample_index, np.uint64)
+        n = len(pixel_xy)
+        rad = np.zeros((n, 3), np.float32); spl = np.zeros((n, 3), np.float32); cnt = np.zeros((n, 3), np.uint32)
+        _check(lib().mi_bpt_trace_paths(self._h, camera_id, width, height, n, _ptr(pixel_xy), _ptr(sample_index), seed, _ptr(rad), _ptr(spl), _ptr(cnt)))
+        return rad, spl, cnt
+
+    def bpt_render_rgbn(self, width, height, spp=1, seed=0, sample_offset=0, camera_id=0):
+        """BPT: `spp` frames of the whole image -> [H][W][4] (R, G, B sums, denom)."""
+        out = np.zeros((height, width, 4), np.float32)
+        st = PtStats()
+        _check(lib().mi_bpt_render(self._h, camera_id, width, height, spp, seed, sample_offset, _ptr(out), C.byref(st)))
+        self.last_stats = st
+        return out
 
     def blob(self):
         """Device scene blob as ([n][4] float32, dict of section offsets in float4 units)."""

@@ -18,6 +18,7 @@ SOURCES = [
     "device/pt_kernels.hip",
     "device/bvh_build.hip",
     "device/wf_kernels.hip",
+    "device/bpt_kernels.hip",
     "scene_host.cpp",
     "blend_reader.cpp",
     "exr_io.cpp",

@@ -11,6 +11,7 @@
 
 #include "device/launch.h"
 #include "device/wavefront.h"
+#include "device/bpt.h"
 #include "scene_host.hpp"
 
 using mi::fail;
@@ -47,6 +48,11 @@ struct mi_pt_handle {
   // wavefront pipeline: one arena for the per-slot arrays
   char* wf_arena = nullptr; size_t wf_arena_bytes = 0;
   uint32_t wf_iterations = 0;
+  // BPT: light sub-path slab, eye / light images of a frame
+  float4* bpt_slab = nullptr; size_t bpt_slab_bytes = 0;
+  float* bpt_eye = nullptr; size_t bpt_eye_bytes = 0;
+  double* bpt_light = nullptr; size_t bpt_light_bytes = 0;
+  float sphere[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -276,6 +282,31 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     h->wide_nodes = nt >= 100000u;
     if (const char* e = std::getenv("MI_PT_WIDE_NODES")) h->wide_nodes = std::atoi(e) != 0;
   }
+  // scene bounding sphere for the emitters' bounded cosine sampling (BPT): the loader's value, or compute_bounding_sphere
+  // (loader.cpp:408-432) over the surface meshes when the description carries none
+  std::memcpy(h->sphere, s.bounding_sphere, sizeof h->sphere);
+  if (!(h->sphere[3] > 0.0f)) {
+    double c[3] = {0, 0, 0}; size_t nv = 0;
+    for (size_t m = 0; m + 1 < s.mesh_tri_offset.size(); ++m) {
+      if ((s.mesh_material_id[m] & 3u) != MI_ENTITY_MESH) continue;
+      for (uint32_t t = s.mesh_tri_offset[m]; t < s.mesh_tri_offset[m + 1]; ++t)
+        for (int k = 0; k < 3; ++k) { const float* q = &s.positions[3 * size_t(s.indices[3 * size_t(t) + k])]; c[0] += q[0]; c[1] += q[1]; c[2] += q[2]; ++nv; }
+    }
+    if (nv) {
+      const float cx = float(c[0] / double(nv)), cy = float(c[1] / double(nv)), cz = float(c[2] / double(nv));
+      float r2 = 0.0f;
+      for (size_t m = 0; m + 1 < s.mesh_tri_offset.size(); ++m) {
+        if ((s.mesh_material_id[m] & 3u) != MI_ENTITY_MESH) continue;
+        for (uint32_t t = s.mesh_tri_offset[m]; t < s.mesh_tri_offset[m + 1]; ++t)
+          for (int k = 0; k < 3; ++k) {
+            const float* q = &s.positions[3 * size_t(s.indices[3 * size_t(t) + k])];
+            const float dx = q[0] - cx, dy = q[1] - cy, dz = q[2] - cz, d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 > r2) r2 = d2;
+          }
+      }
+      h->sphere[0] = cx; h->sphere[1] = cy; h->sphere[2] = cz; h->sphere[3] = std::sqrt(r2);
+    }
+  }
   h->lds_fits = size_t(sv.blob_f4 + sv.n_nodes + sv.n_tris) * 16 <= kLdsSceneLimit;  // the LDS copy pads nodes and shading records by one float4
   guard.h = nullptr;
   *out = h;
@@ -292,6 +323,9 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->d_morton) hipFree(h->d_morton);
   if (h->partial) hipFree(h->partial);
   if (h->wf_arena) hipFree(h->wf_arena);
+  if (h->bpt_slab) hipFree(h->bpt_slab);
+  if (h->bpt_eye) hipFree(h->bpt_eye);
+  if (h->bpt_light) hipFree(h->bpt_light);
   if (h->d_rgbn) hipFree(h->d_rgbn);
   if (h->d_counters) hipFree(h->d_counters);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -508,6 +542,119 @@ int mi_pt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint3
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_radiance, d_r, size_t(n) * 12, hipMemcpyDeviceToHost));
   if (out_ray_counts) HIP_TRY(hipMemcpy(out_ray_counts, d_c, size_t(n) * 8, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+namespace {
+// buffers and per-launch constants shared by the two BPT entry points
+int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint64_t total_lanes, mi::RenderParams& p, mi::BptState& w,
+                uint32_t* lanes_per_launch) {
+  std::memset(&p, 0, sizeof p); std::memset(&w, 0, sizeof w);
+  int rc = fill_camera(h, camera_id, width, height, p);
+  if (rc) return rc;
+  fill_pt(h, p);
+  p.stack_entries = h->stack_entries_hbm;  // the BPT kernels read the scene from HBM
+  mi_camera_frame fr;
+  rc = mi_camera_setup(&h->scene.cameras[camera_id], float(width) / float(height), &fr);
+  if (rc) return rc;
+  std::memcpy(w.w2v, fr.world_to_view, sizeof w.w2v);
+  std::memcpy(w.sphere, h->sphere, sizeof w.sphere);
+  uint64_t lanes = total_lanes < (1ull << 18) ? total_lanes : (1ull << 18);
+  lanes = (lanes + 255) / 256 * 256;
+  uint64_t cap = (6ull << 30) / (lanes * 112ull);
+  if (cap > 1024) cap = 1024;
+  if (cap < 64) cap = 64;
+  rc = ensure(reinterpret_cast<void**>(&h->bpt_slab), &h->bpt_slab_bytes, size_t(lanes) * cap * 112);
+  if (rc) return rc;
+  w.slab = h->bpt_slab; w.max_vertices = uint32_t(cap);
+  *lanes_per_launch = uint32_t(lanes);
+  p.counters = h->d_counters;
+  return MI_OK;
+}
+}  // namespace
+
+int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint64_t sample_offset,
+                  float* rgbn_sum, mi_pt_stats* stats) {
+  if (!h || !rgbn_sum) return fail(MI_ERR_INVALID_ARGUMENT, "mi_bpt_render: null argument");
+  if (spp == 0) return fail(MI_ERR_INVALID_ARGUMENT, "spp must be > 0");
+  HIP_TRY(hipSetDevice(h->device));
+  mi::RenderParams p; mi::BptState w; uint32_t per_launch = 0;
+  const uint64_t tiles_x = (uint64_t(width) + 7) / 8, tiles_y = (uint64_t(height) + 7) / 8, total = tiles_x * tiles_y * 64;
+  int rc = bpt_prepare(h, camera_id, width, height, total, p, w, &per_launch);
+  if (rc) return rc;
+  p.win_x0 = 0; p.win_y0 = 0; p.win_w = width; p.win_h = height; p.tiles_x = uint32_t(tiles_x); p.tiles_y = uint32_t(tiles_y);
+  p.spp = spp; p.seed = seed; p.sample_offset = sample_offset; p.n_chunks = 1;
+  const size_t np = size_t(width) * height;
+  rc = ensure(reinterpret_cast<void**>(&h->partial), &h->partial_bytes, np * 32); if (rc) return rc;
+  rc = ensure(reinterpret_cast<void**>(&h->bpt_eye), &h->bpt_eye_bytes, np * 12); if (rc) return rc;
+  rc = ensure(reinterpret_cast<void**>(&h->bpt_light), &h->bpt_light_bytes, np * 24); if (rc) return rc;
+  rc = ensure(reinterpret_cast<void**>(&h->d_rgbn), &h->rgbn_bytes, np * 16); if (rc) return rc;
+  p.partial = h->partial; w.eye = h->bpt_eye; w.light = h->bpt_light;
+  hipStream_t stream = h->stream;
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(h->partial, 0, np * 32, stream));
+  HIP_TRY(hipMemsetAsync(h->bpt_eye, 0, np * 12, stream));
+  HIP_TRY(hipMemsetAsync(h->bpt_light, 0, np * 24, stream));
+  HIP_TRY(hipEventRecord(h->ev0, stream));
+  for (uint32_t f = 0; f < spp; ++f) {
+    w.frame = f;
+    for (uint64_t first = 0; first < total; first += per_launch) {
+      w.first = uint32_t(first); w.lanes = uint32_t(total - first < per_launch ? total - first : per_launch);
+      HIP_TRY(mi::bpt_launch_frame(p, w, false, stream));
+    }
+    HIP_TRY(mi::bpt_launch_commit(p, w, stream));
+  }
+  HIP_TRY(hipEventRecord(h->ev1, stream));
+  HIP_TRY(mi::launch_finalize(h->partial, h->d_rgbn, width, height, 0, 0, width, height, 1, stream));
+  HIP_TRY(hipEventRecord(h->ev2, stream));
+  unsigned long long c[24];
+  HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(rgbn_sum, h->d_rgbn, np * 16, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (c[15]) return fail(MI_ERR_UNSUPPORTED, "BPT: " + std::to_string(c[15]) + " light sub-paths exceeded the vertex slab");
+  if (stats) {
+    float t01 = 0.0f, t02 = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&t01, h->ev0, h->ev1));
+    HIP_TRY(hipEventElapsedTime(&t02, h->ev0, h->ev2));
+    std::memset(stats, 0, sizeof *stats);
+    stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
+    stats->trace_ms = t01; stats->gpu_ms = t02;
+  }
+  return MI_OK;
+}
+
+int mi_bpt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_xy,
+                       const uint64_t* sample_index, uint64_t seed, float* out_radiance, float* out_splat_sum, uint32_t* out_counts3) {
+  if (!h || (n && (!pixel_xy || !sample_index || !out_radiance))) return fail(MI_ERR_INVALID_ARGUMENT, "mi_bpt_trace_paths: null argument");
+  if (n == 0) return MI_OK;
+  for (uint32_t i = 0; i < n; ++i)
+    if (pixel_xy[2 * i] >= width || pixel_xy[2 * i + 1] >= height) return fail(MI_ERR_INVALID_ARGUMENT, "pixel outside the image");
+  HIP_TRY(hipSetDevice(h->device));
+  mi::RenderParams p; mi::BptState w; uint32_t per_launch = 0;
+  int rc = bpt_prepare(h, camera_id, width, height, n, p, w, &per_launch);
+  if (rc) return rc;
+  uint32_t *d_xy = nullptr, *d_c = nullptr; uint64_t* d_s = nullptr; float *d_r = nullptr, *d_sp = nullptr;
+  struct Tmp { void* p[5]; ~Tmp() { for (void* q : p) if (q) hipFree(q); } } tmp{{nullptr, nullptr, nullptr, nullptr, nullptr}};
+  rc = upload(&d_xy, pixel_xy, size_t(n) * 8); tmp.p[0] = d_xy; if (rc) return rc;
+  rc = upload(&d_s, sample_index, size_t(n) * 8); tmp.p[1] = d_s; if (rc) return rc;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_r), size_t(n) * 12)); tmp.p[2] = d_r;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_sp), size_t(n) * 12)); tmp.p[3] = d_sp;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_c), size_t(n) * 12)); tmp.p[4] = d_c;
+  p.win_w = width; p.win_h = height; p.seed = seed;
+  p.list_xy = d_xy; p.list_sample = d_s; p.list_n = n; p.list_radiance = d_r;
+  w.list_splat_sum = d_sp; w.list_counts3 = d_c;
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), h->stream));
+  for (uint64_t first = 0; first < n; first += per_launch) {
+    w.first = uint32_t(first); w.lanes = uint32_t(n - first < per_launch ? n - first : per_launch);
+    HIP_TRY(mi::bpt_launch_frame(p, w, true, h->stream));
+  }
+  unsigned long long c[24];
+  HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (c[15]) return fail(MI_ERR_UNSUPPORTED, "BPT: " + std::to_string(c[15]) + " light sub-paths exceeded the vertex slab");
+  HIP_TRY(hipMemcpy(out_radiance, d_r, size_t(n) * 12, hipMemcpyDeviceToHost));
+  if (out_splat_sum) HIP_TRY(hipMemcpy(out_splat_sum, d_sp, size_t(n) * 12, hipMemcpyDeviceToHost));
+  if (out_counts3) HIP_TRY(hipMemcpy(out_counts3, d_c, size_t(n) * 12, hipMemcpyDeviceToHost));
   return MI_OK;
 }
 

@@ -130,6 +130,38 @@ static inline void sincos_2pi(float u, float* s, float* c) {
   *c = (q == 1 || q == 2) ? -co : co;
 }
 
+
+/* asin, atan2 and sin/cos of an angle in radians for the bounded cosine sampling of the emitters (Sample.inl:5-37,62-137).
+ * DEFINED here (Cephes asinf / atanf kernels, every step an explicit fma or a single operation) and stated identically on the
+ * device, like sincos_2pi: libm and the device library differ in the last bits.  |error| ~ 1e-7. */
+static inline float mi_asinf(float x) {
+  float a = fabsf(x), z, xs; int big = a > 0.5f;
+  if (big) { z = 0.5f * (1.0f - a); xs = sqrtf(z); } else { xs = a; z = a * a; }
+  float p = fmaf(fmaf(fmaf(fmaf(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z, 1.6666752422e-1f);
+  float r = fmaf(p * z, xs, xs);
+  if (big) r = 1.57079632679489661923f - (r + r);
+  return x < 0.0f ? -r : r;
+}
+static inline float mi_atanf(float t) {
+  float x = fabsf(t), y;
+  if (x > 2.414213562373095f) { y = 1.57079632679489661923f; x = -(1.0f / x); }
+  else if (x > 0.4142135623730950f) { y = 0.785398163397448309616f; x = (x - 1.0f) / (x + 1.0f); }
+  else y = 0.0f;
+  float z = x * x;
+  float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+  y = y + fmaf(p * z, x, x);
+  return t < 0.0f ? -y : y;
+}
+static inline float mi_atan2f(float y, float x) {
+  if (x > 0.0f) return mi_atanf(y / x);
+  if (x < 0.0f) return y < 0.0f ? mi_atanf(y / x) - 3.14159265358979323846f : mi_atanf(y / x) + 3.14159265358979323846f;
+  return y > 0.0f ? 1.57079632679489661923f : (y < 0.0f ? -1.57079632679489661923f : 0.0f);
+}
+static inline void mi_sincosf(float rad, float* s, float* c) {
+  float t = rad * 0.159154943091895335769f; /* turns */
+  sincos_2pi(t - floorf(t), s, c);
+}
+
 /* ------------------------------------------------------------------ RNG (defined here) */
 typedef struct { uint64_t state; } rng_t;
 #define PCG_MULT 6364136223846793005ULL

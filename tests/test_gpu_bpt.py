@@ -1,0 +1,94 @@
+"""GPU parity of the BPT kernels against the BPT oracle, through the C ABI (mi_bpt_*).
+Bit-exact per path wherever no library pow() is involved (Phong lobes, VariableBeta): eye-image radiance, the sum of the
+light-image splats, closest-hit / shadow ray counts and the number of splats."""
+import os
+
+import numpy as np
+import pytest
+
+import master_amd as ma
+import oracle
+from conftest import load_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _paths(w, h, n, seed):
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], 1).astype(np.uint32), rng.integers(0, 32, n).astype(np.uint64)
+
+
+def _bits_equal(a, b):
+    return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all(1)
+
+
+def _corpus():
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scenes")
+    return sorted(f[:-8] for f in os.listdir(d) if f.endswith(".miscene") and os.path.getsize(os.path.join(d, f)) < 1000000)
+
+
+@pytest.mark.parametrize("name", _corpus())
+def test_bpt_reference_corpus_parity(name):
+    s = load_scene(name)
+    pt, orc = ma.PathTracing(s, beta=2.0), oracle.Oracle(s, beta=2.0)
+    xy, si = _paths(64, 48, 5000, 5)
+    gr, gs, gc = pt.bpt_trace_paths(64, 48, xy, si, seed=7); orr, os_, oc = orc.bpt_trace_paths(64, 48, xy, si, seed=7)
+    if any(m.type == ma.BSDF_PHONG for m in s.materials):  # library powf on both sides: stated tolerance 5e-5, rare divergent paths
+        assert (gc == oc).all(1).mean() > 0.99
+        assert np.isclose(gr, orr, rtol=5e-5, atol=1e-6, equal_nan=True).all(1).mean() > 0.99
+        assert np.isclose(gs, os_, rtol=5e-5, atol=1e-6, equal_nan=True).all(1).mean() > 0.99
+    else:
+        assert np.array_equal(gc, oc)
+        assert _bits_equal(gr, orr).all() and _bits_equal(gs, os_).all()
+
+
+@pytest.mark.parametrize("beta", [0.0, 1.0, 2.0, 1.5])
+def test_bpt_beta_variants(cornell, beta):
+    pt, orc = ma.PathTracing(cornell, beta=beta, roulette=0.8), oracle.Oracle(cornell, beta=beta, roulette=0.8)
+    xy, si = _paths(48, 48, 6000, 9)
+    gr, gs, gc = pt.bpt_trace_paths(48, 48, xy, si, seed=3); orr, os_, oc = orc.bpt_trace_paths(48, 48, xy, si, seed=3)
+    assert np.array_equal(gc, oc)
+    if beta in (0.0, 1.0, 2.0):
+        assert _bits_equal(gr, orr).all() and _bits_equal(gs, os_).all()
+    else:  # VariableBeta: pow() through the math libraries
+        assert np.isclose(gr, orr, rtol=5e-5, atol=1e-7).all() and np.isclose(gs, os_, rtol=5e-5, atol=1e-7).all()
+
+
+@pytest.mark.parametrize("name,w,h", [("CornellBoxDiffuse", 64, 48), ("TestCase10", 37, 23), ("CornellBoxSpecular", 40, 40)])
+def test_bpt_render_equals_oracle(name, w, h):
+    """Frames: eye image + light image, one finite filter per pixel and frame (Technique.cpp:194-244); ragged sizes."""
+    s = load_scene(name)
+    pt, orc = ma.PathTracing(s, beta=2.0), oracle.Oracle(s, beta=2.0)
+    img = pt.bpt_render_rgbn(w, h, spp=12, seed=5, sample_offset=2); ref = orc.bpt_render_rgbn(w, h, spp=12, seed=5, sample_offset=2, threads=8)
+    st, so = pt.last_stats, orc.last_stats
+    assert (st.num_paths, st.num_basic_rays, st.num_shadow_rays, st.numeric_errors) == (so.num_paths, so.num_basic_rays, so.num_shadow_rays, so.numeric_errors)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    np.testing.assert_allclose(img, ref, rtol=2e-6, atol=0)  # FP64 splat order is free; everything else is exact
+    again = pt.bpt_render_rgbn(w, h, spp=12, seed=5, sample_offset=2)
+    np.testing.assert_allclose(img, again, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", ["TestCase0", "TestCase9", "TestCase10", "TestCase18", "TestCaseFurnace"])
+def test_bpt_normalised_models_average_one_on_device(name):
+    s = load_scene(name)
+    img = ma.PathTracing(s, beta=2.0).bpt_render_rgbn(96, 96, spp=96, seed=1)
+    m = float((img[..., :3] / np.maximum(img[..., 3:], 1)).mean())
+    assert abs(m - 1.0) < 0.02, m
+
+
+def test_bpt_and_pt_converge_to_the_same_image(cornell):
+    pt = ma.PathTracing(cornell, beta=2.0, max_path=ma.PTRDIFF_MAX)
+    b = pt.bpt_render_rgbn(64, 64, spp=512, seed=1); p = pt.render_rgbn(64, 64, spp=512, seed=2)
+    br, pr = b[..., :3] / b[..., 3:], p[..., :3] / p[..., 3:]
+    assert abs(br.mean() - pr.mean()) / pr.mean() < 0.01
+    assert np.sqrt(np.mean((br - pr) ** 2)) < 0.05
+
+
+def test_bpt_error_behaviour(cornell):
+    pt = ma.PathTracing(cornell)
+    with pytest.raises(ma.MiError):
+        pt.bpt_render_rgbn(16, 16, spp=0)
+    with pytest.raises(ma.MiError):
+        pt.bpt_trace_paths(16, 16, np.array([[16, 0]], np.uint32), np.array([0], np.uint64))
+    with pytest.raises(ma.MiError):
+        pt.bpt_render_rgbn(16, 16, spp=1, camera_id=5)

@@ -10,11 +10,12 @@ namespace mi {
 struct BptState {
   uint32_t lanes;          // paths of this launch (one lane each)
   uint32_t first;          // image mode: first lane's index in tile order; list mode: first list item
-  uint32_t frame;          // image mode: sample index of this frame (added to RenderParams::sample_offset)
+  uint32_t frame;          // image mode: sample index of the first frame of this batch (added to RenderParams::sample_offset)
+  uint32_t frames;         // image mode: frames in this batch (each with its own eye / light image)
   uint32_t max_vertices;   // capacity of a lane's light sub-path (BPT.hpp:30 allows 1024)
   float4* slab;            // [max_vertices][7][lanes] light sub-path vertices
-  float* eye;              // [H][W][3] eye image of the frame (Technique::_eye_image)
-  double* light;           // [H][W][3] light image of the frame (Technique::_light_image)
+  float* eye;              // [frames][H][W][3] eye images (Technique::_eye_image)
+  double* light;           // [frames][H][W][3] light images (Technique::_light_image)
   float sphere[4];         // scene bounding sphere (loader.cpp:408-432) for the emitters' bounded cosine sampling
   float w2v[9];            // world_to_view_mat3 (Technique.cpp:40)
   float* list_splat_sum; uint32_t* list_counts3;  // list mode outputs (mi_bpt_trace_paths)

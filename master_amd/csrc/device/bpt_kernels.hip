@@ -370,25 +370,31 @@ MI_DEV f3 bpt_trace_eye(Ctx& c, Rng& g, const Cam& cam, const Surf& camera_surfa
 }  // namespace
 
 // one lane = one (pixel, sample): shoot() + _traceEye (Technique.cpp:321-338)
+#ifndef MI_BPT_WAVES
+#define MI_BPT_WAVES 3  // 201 VGPRs without a bound (2 waves); measured on C2-sized BPT frames: 2 waves 804, 3 waves 894, 4 waves 872, 5 waves 754 Mrays/s
+#endif
 template <bool LIST, int QN>
-__global__ __launch_bounds__(kBlock) void bpt_frame(const RenderParams p, const BptState w) {
+__global__ __launch_bounds__(kBlock, MI_BPT_WAVES) void bpt_frame(const RenderParams p, const BptState w) {
   extern __shared__ float4 smem[];
   TravStack stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
   stack.cap = p.stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  uint32_t px = 0, py = 0; uint64_t sample = 0; bool ok = false;
+  uint32_t px = 0, py = 0, fl = 0; uint64_t sample = 0; bool ok = false;
   if (LIST) {
     const uint64_t item = w.first + i;
     ok = i < w.lanes && item < p.list_n;
     if (ok) { px = p.list_xy[2 * item]; py = p.list_xy[2 * item + 1]; sample = p.list_sample[item]; }
   } else {
-    // lane -> pixel in 8x8 tiles of the window (coherent camera rays in a wave)
-    const uint32_t gi = w.first + i, tile = gi >> 6, pix = gi & 63u;
+    // lane -> (frame of the batch, pixel in 8x8 tiles of the window): coherent camera rays in a wave
+    const uint32_t per_frame = p.tiles_x * p.tiles_y * 64u;
+    const uint32_t gi = w.first + i;
+    fl = gi / per_frame;
+    const uint32_t rem = gi - fl * per_frame, tile = rem >> 6, pix = rem & 63u;
     const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     px = p.win_x0 + tx * 8u + (pix & 7u); py = p.win_y0 + ty * 8u + (pix >> 3);
-    sample = p.sample_offset + w.frame;
-    ok = i < w.lanes && ty < p.tiles_y && px < p.win_x0 + p.win_w && py < p.win_y0 + p.win_h;
+    sample = p.sample_offset + w.frame + fl;
+    ok = i < w.lanes && fl < w.frames && px < p.win_x0 + p.win_w && py < p.win_y0 + p.win_h;
   }
   bool overflow = false;
   uint32_t nb = 0, ns = 0;
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void bpt_frame(const RenderParams p, const 
     const float vy = fy * p.res_y_inv * 2.0f - 1.0f;
     const f3 dir = mulmv(v2w, normalize(F3(vx, vy, -p.focal_length_y)));
     Slab slab; slab.base = w.slab; slab.lanes = w.lanes; slab.lane = i; slab.cap = w.max_vertices;
-    SplatOut sp; sp.light = LIST ? nullptr : w.light; sp.n = 0; sp.sum = F3(0, 0, 0);
+    SplatOut sp; sp.light = LIST ? nullptr : w.light + size_t(fl) * 3 * p.width * p.height; sp.n = 0; sp.sum = F3(0, 0, 0);
     const f3 r = bpt_trace_eye<QN>(c, rng, cam, cs, dir, slab, sp, overflow);
     nb = c.n_basic; ns = c.n_shadow;
     if (LIST) {
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void bpt_frame(const RenderParams p, const 
       w.list_splat_sum[3 * item] = sp.sum.x; w.list_splat_sum[3 * item + 1] = sp.sum.y; w.list_splat_sum[3 * item + 2] = sp.sum.z;
       w.list_counts3[3 * item] = nb; w.list_counts3[3 * item + 1] = ns; w.list_counts3[3 * item + 2] = sp.n;
     } else {
-      float* e = w.eye + 3 * (size_t(py) * p.width + px);
+      float* e = w.eye + 3 * (size_t(fl) * p.width * p.height + size_t(py) * p.width + px);
       e[0] = r.x; e[1] = r.y; e[2] = r.z;
     }
   }
@@ -438,27 +444,27 @@ __global__ __launch_bounds__(kBlock) void bpt_frame(const RenderParams p, const 
   }
 }
 
-// Technique::_commit_images (Technique.cpp:194-244) for one frame
+// Technique::_commit_images (Technique.cpp:194-244) for the frames of a batch, in frame order
 __global__ __launch_bounds__(256) void bpt_commit(const RenderParams p, const BptState w) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  bool err = false;
+  uint32_t errors = 0;
   if (i < p.width * p.height) {
     const uint32_t y = i / p.width, x = i - y * p.width;
-    if (x >= p.win_x0 && x < p.win_x0 + p.win_w && y >= p.win_y0 && y < p.win_y0 + p.win_h) {
-      double* l = w.light + 3 * size_t(i); float* e = w.eye + 3 * size_t(i);
-      const double v0 = l[0] + double(e[0]), v1 = l[1] + double(e[1]), v2 = l[2] + double(e[2]);
-      if (isfinite(fabs(v0) + fabs(v1) + fabs(v2))) {
-        double* o = p.partial + 4 * size_t(i);
-        o[0] += v0; o[1] += v1; o[2] += v2; o[3] += 1.0;
-      } else err = true;
+    const bool inside = x >= p.win_x0 && x < p.win_x0 + p.win_w && y >= p.win_y0 && y < p.win_y0 + p.win_h;
+    double* o = p.partial + 4 * size_t(i);
+    double a0 = o[0], a1 = o[1], a2 = o[2], a3 = o[3];
+    for (uint32_t f = 0; f < w.frames; ++f) {
+      double* l = w.light + 3 * (size_t(f) * p.width * p.height + i); float* e = w.eye + 3 * (size_t(f) * p.width * p.height + i);
+      if (inside) {
+        const double v0 = l[0] + double(e[0]), v1 = l[1] + double(e[1]), v2 = l[2] + double(e[2]);
+        if (isfinite(fabs(v0) + fabs(v1) + fabs(v2))) { a0 += v0; a1 += v1; a2 += v2; a3 += 1.0; } else ++errors;
+      }
       l[0] = l[1] = l[2] = 0.0; e[0] = e[1] = e[2] = 0.0f;
-    } else {
-      double* l = w.light + 3 * size_t(i);  // splats outside the window are not part of the view (the reference renders whole images with BPT)
-      l[0] = l[1] = l[2] = 0.0;
     }
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
   }
-  const uint64_t m = __ballot(err);
-  if (m != 0ull && p.counters && (threadIdx.x & 63u) == uint32_t(__ffsll((long long)m) - 1)) atomicAdd(&p.counters[2], (unsigned long long)__popcll(m));
+  for (int k = 32; k > 0; k >>= 1) errors += __shfl_xor(errors, k, 64);
+  if (errors && p.counters && (threadIdx.x & 63u) == 0) atomicAdd(&p.counters[2], (unsigned long long)errors);
 }
 
 hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list, hipStream_t stream) {

@@ -559,9 +559,9 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   if (rc) return rc;
   std::memcpy(w.w2v, fr.world_to_view, sizeof w.w2v);
   std::memcpy(w.sphere, h->sphere, sizeof w.sphere);
-  uint64_t lanes = total_lanes < (1ull << 18) ? total_lanes : (1ull << 18);
+  uint64_t lanes = total_lanes < (1ull << 20) ? total_lanes : (1ull << 20);  // up to 1 M paths per launch
   lanes = (lanes + 255) / 256 * 256;
-  uint64_t cap = (6ull << 30) / (lanes * 112ull);
+  uint64_t cap = (24ull << 30) / (lanes * 112ull);  // light sub-path slab: up to 24 GB of the 288 GB
   if (cap > 1024) cap = 1024;
   if (cap < 64) cap = 64;
   rc = ensure(reinterpret_cast<void**>(&h->bpt_slab), &h->bpt_slab_bytes, size_t(lanes) * cap * 112);
@@ -586,20 +586,26 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
   p.spp = spp; p.seed = seed; p.sample_offset = sample_offset; p.n_chunks = 1;
   const size_t np = size_t(width) * height;
   rc = ensure(reinterpret_cast<void**>(&h->partial), &h->partial_bytes, np * 32); if (rc) return rc;
-  rc = ensure(reinterpret_cast<void**>(&h->bpt_eye), &h->bpt_eye_bytes, np * 12); if (rc) return rc;
-  rc = ensure(reinterpret_cast<void**>(&h->bpt_light), &h->bpt_light_bytes, np * 24); if (rc) return rc;
+  // frames are rendered in batches: each frame of a batch has its own eye / light image; the commit walks them in frame order
+  uint64_t batch = per_launch / total;
+  if (batch < 1) batch = 1;
+  if (batch > spp) batch = spp;
+  if (batch > 64) batch = 64;
+  rc = ensure(reinterpret_cast<void**>(&h->bpt_eye), &h->bpt_eye_bytes, np * 12 * batch); if (rc) return rc;
+  rc = ensure(reinterpret_cast<void**>(&h->bpt_light), &h->bpt_light_bytes, np * 24 * batch); if (rc) return rc;
   rc = ensure(reinterpret_cast<void**>(&h->d_rgbn), &h->rgbn_bytes, np * 16); if (rc) return rc;
   p.partial = h->partial; w.eye = h->bpt_eye; w.light = h->bpt_light;
   hipStream_t stream = h->stream;
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), stream));
   HIP_TRY(hipMemsetAsync(h->partial, 0, np * 32, stream));
-  HIP_TRY(hipMemsetAsync(h->bpt_eye, 0, np * 12, stream));
-  HIP_TRY(hipMemsetAsync(h->bpt_light, 0, np * 24, stream));
+  HIP_TRY(hipMemsetAsync(h->bpt_eye, 0, np * 12 * batch, stream));
+  HIP_TRY(hipMemsetAsync(h->bpt_light, 0, np * 24 * batch, stream));
   HIP_TRY(hipEventRecord(h->ev0, stream));
-  for (uint32_t f = 0; f < spp; ++f) {
-    w.frame = f;
-    for (uint64_t first = 0; first < total; first += per_launch) {
-      w.first = uint32_t(first); w.lanes = uint32_t(total - first < per_launch ? total - first : per_launch);
+  for (uint32_t f = 0; f < spp; f += uint32_t(batch)) {
+    w.frame = f; w.frames = uint32_t(spp - f < batch ? spp - f : batch);
+    const uint64_t lanes_total = total * w.frames;
+    for (uint64_t first = 0; first < lanes_total; first += per_launch) {
+      w.first = uint32_t(first); w.lanes = uint32_t(lanes_total - first < per_launch ? lanes_total - first : per_launch);
       HIP_TRY(mi::bpt_launch_frame(p, w, false, stream));
     }
     HIP_TRY(mi::bpt_launch_commit(p, w, stream));

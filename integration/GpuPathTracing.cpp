@@ -28,8 +28,8 @@ mi_material flatten(const BSDF& bsdf) {
 }  // namespace
 
 GpuPathTracing::GpuPathTracing(const shared<const Scene>& scene, float lights, float roulette, float beta,
-                               size_t max_path, size_t num_threads, int device)
-    : Technique(scene, 1) {
+                               size_t max_path, size_t num_threads, int device, bool bidirectional)
+    : Technique(scene, 1), _bidirectional(bidirectional) {
   (void)num_threads;
   std::vector<float> positions, tangents;
   std::vector<uint32_t> indices, offsets{0}, mesh_material;
@@ -68,7 +68,7 @@ GpuPathTracing::GpuPathTracing(const shared<const Scene>& scene, float lights, f
   d.mesh_tri_offset = offsets.data(); d.mesh_material_id = mesh_material.data();
   d.materials = materials.data(); d.lights = mlights.data(); d.cameras = cams.data();
   mi_pt_params p = {uint64_t(max_path), beta, roulette, lights, 3};
-  check(mi_pt_create(&d, &p, device, &_handle));          // copies the scene, builds the LBVH on the GPU
+  check(mi_pt_create(&d, &p, device, &_handle));          // copies the scene, builds the BVH on the GPU; a zero bounding_sphere is computed as loader.cpp:408-432
   _seed = std::random_device()();                          // like Sample.inl:249-252: PT is not seedable
 }
 
@@ -84,8 +84,12 @@ void GpuPathTracing::render(subimage_view_t& view, RandomEngine&, size_t cameraI
   _rgbn.resize(view.width() * view.height() * 4);
   mi_window win = {uint32_t(view.xBegin()), uint32_t(view.yBegin()), uint32_t(view.xWindow()), uint32_t(view.yWindow())};
   mi_pt_stats st = {};
-  check(mi_pt_render(_handle, uint32_t(cameraId), uint32_t(view.width()), uint32_t(view.height()), win,
-                     /*spp=*/1, _seed, /*sample_offset=*/_statistics.num_samples, _rgbn.data(), &st));
+  if (_bidirectional)  // BPT renders whole frames (light-image splats land anywhere); light + eye are committed per frame inside
+    check(mi_bpt_render(_handle, uint32_t(cameraId), uint32_t(view.width()), uint32_t(view.height()),
+                        /*spp=*/1, _seed, /*sample_offset=*/_statistics.num_samples, _rgbn.data(), &st));
+  else
+    check(mi_pt_render(_handle, uint32_t(cameraId), uint32_t(view.width()), uint32_t(view.height()), win,
+                       /*spp=*/1, _seed, /*sample_offset=*/_statistics.num_samples, _rgbn.data(), &st));
   for (size_t y = view.yBegin(); y < view.yEnd(); ++y)    // _commit_images (Technique.cpp:215-236)
     for (size_t x = view.xBegin(); x < view.xEnd(); ++x) {
       const float* s = &_rgbn[(y * view.width() + x) * 4];

@@ -10,8 +10,9 @@ namespace haste {
 class GpuPathTracing : public Technique {
  public:
   // same arguments as PathTracing (PT.cpp:5-13); num_threads is ignored, `device` selects the GPU
+  // `bidirectional` = the BPT0/1/2/b techniques (make_technique.cpp:112-130) through mi_bpt_render: beta 0 / 1 / 2 / other
   GpuPathTracing(const shared<const Scene>& scene, float lights, float roulette, float beta,
-                 size_t max_path, size_t num_threads, int device = 0);
+                 size_t max_path, size_t num_threads, int device = 0, bool bidirectional = false);
   ~GpuPathTracing() override;
 
   // Technique::render replaced wholesale (precedent: Viewer::render, Viewer.cpp:14-23)
@@ -22,6 +23,7 @@ class GpuPathTracing : public Technique {
   mi_pt_handle* _handle = nullptr;
   std::vector<float> _rgbn;
   uint64_t _seed;
+  bool _bidirectional = false;
 };
 
 }  // namespace haste

@@ -13,7 +13,14 @@ struct BptState {
   uint32_t frame;          // image mode: sample index of the first frame of this batch (added to RenderParams::sample_offset)
   uint32_t frames;         // image mode: frames in this batch (each with its own eye / light image)
   uint32_t max_vertices;   // capacity of a lane's light sub-path (BPT.hpp:30 allows 1024)
-  float4* slab;            // [max_vertices][7][lanes] light sub-path vertices
+  float4* slab;            // one-kernel form: [max_vertices][7][lanes] light sub-path vertices
+  // staged form: path-major records (7 float4 per vertex), emission terms, per-path info, item offsets and values
+  float4* lslab; float4* eslab; float4* nslab;   // [lanes][max_vertices][7]: light vertices, eye vertices, NEE samples of the eye vertices
+  float4* emission;        // [lanes][max_vertices]: emission terms of the eye sub-path (rgb | index of the eye vertex they follow)
+  uint4* info;             // [lanes][2]: (L, E, items, emission terms), (closest-hit rays of the tracing stage, directional NEE, py<<16|px, frame<<1|ok)
+  uint32_t* item_offset;   // [lanes + 1]: first connection item of every path (exclusive scan of the counts)
+  uint32_t* scan_tmp;      // [ceil((lanes + 1) / 2048)]: tile totals of that scan
+  float4* values;          // [items]: value of a connection | flags
   float* eye;              // [frames][H][W][3] eye images (Technique::_eye_image)
   double* light;           // [frames][H][W][3] light images (Technique::_light_image)
   float sphere[4];         // scene bounding sphere (loader.cpp:408-432) for the emitters' bounded cosine sampling
@@ -22,6 +29,8 @@ struct BptState {
 };
 
 hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list, hipStream_t stream);
+hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, hipStream_t stream, uint32_t* total_items);
+hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, uint32_t total_items, hipStream_t stream);
 hipError_t bpt_launch_commit(const RenderParams& p, const BptState& w, hipStream_t stream);
 
 }  // namespace mi

@@ -367,6 +367,370 @@ MI_DEV f3 bpt_trace_eye(Ctx& c, Rng& g, const Cam& cam, const Surf& camera_surfa
   }
 }
 
+
+// =====================================================================================================================
+// Staged form (default): the same arithmetic cut into three kernels so that the connections — the bulk of BPT's rays, one
+// shadow ray each — run as a flat list of independent work items instead of inside the lane that traced the path.
+//   bpt_trace     per lane: roulette, light sub-path, eye sub-path (every RNG draw in the reference's order, emission terms of
+//                 _connect_light inline), vertices to path-major slabs in HBM; counts the path's connection items
+//   (scan)        item offsets per path
+//   bpt_items     one lane per item: (camera vertex, light vertex i) -> light-image splat; (eye vertex k, NEE sample) and
+//                 (eye vertex k, light vertex i >= 1) -> value slot
+//   bpt_gather    per path: the float sums in the reference's order (BPT.cpp:275-293 sums a vertex's connections locally,
+//                 then adds them to the path's radiance; emission terms follow), eye image / list outputs, ray counts
+// =====================================================================================================================
+
+// path-major vertex records: 7 float4 per vertex, a path's vertices contiguous (an item's two vertices are two 112-byte reads)
+MI_DEV void rec_store_l(float4* base, const LVert& x) {
+  base[0] = make_float4(x.surface.position.x, x.surface.position.y, x.surface.position.z, x.a);
+  base[1] = make_float4(x.surface.gnormal.x, x.surface.gnormal.y, x.surface.gnormal.z, x.A);
+  base[2] = make_float4(x.surface.tangent.c0.x, x.surface.tangent.c0.y, x.surface.tangent.c0.z, __int_as_float(x.finite));
+  base[3] = make_float4(x.surface.tangent.c1.x, x.surface.tangent.c1.y, x.surface.tangent.c1.z, __uint_as_float(x.surface.material_id));
+  base[4] = make_float4(x.surface.tangent.c2.x, x.surface.tangent.c2.y, x.surface.tangent.c2.z, 0.f);
+  base[5] = make_float4(x.omega.x, x.omega.y, x.omega.z, 0.f);
+  base[6] = make_float4(x.throughput.x, x.throughput.y, x.throughput.z, 0.f);
+}
+MI_DEV LVert rec_load_l(const float4* base) {
+  const float4 q0 = base[0], q1 = base[1], q2 = base[2], q3 = base[3], q4 = base[4], q5 = base[5], q6 = base[6];
+  LVert x;
+  x.surface.position = xyz(q0); x.a = q0.w;
+  x.surface.gnormal = xyz(q1); x.A = q1.w;
+  x.surface.tangent.c0 = xyz(q2); x.finite = __float_as_int(q2.w);
+  x.surface.tangent.c1 = xyz(q3); x.surface.material_id = __float_as_uint(q3.w);
+  x.surface.tangent.c2 = xyz(q4);
+  x.omega = xyz(q5); x.throughput = xyz(q6);
+  return x;
+}
+// eye vertex: like a light vertex with (c, C); .w of records 4 / 5 carry the NEE kind (0 none, 1 area, 2 directional) and the
+// vertex's first item (offset inside the path's item range)
+MI_DEV void rec_store_e(float4* base, const EVert& x, uint32_t nee_kind, uint32_t item0) {
+  LVert t; t.surface = x.surface; t.omega = x.omega; t.throughput = x.throughput; t.a = x.c; t.A = x.C; t.finite = x.finite;
+  rec_store_l(base, t);
+  base[4].w = __uint_as_float(nee_kind); base[5].w = __uint_as_float(item0);
+}
+MI_DEV EVert rec_load_e(const float4* base, uint32_t& nee_kind, uint32_t& item0) {
+  const LVert t = rec_load_l(base);
+  nee_kind = __float_as_uint(base[4].w); item0 = __float_as_uint(base[5].w);
+  EVert x; x.surface = t.surface; x.omega = t.omega; x.throughput = t.throughput; x.c = t.a; x.C = t.A; x.finite = t.finite;
+  return x;
+}
+// directional NEE sample (BPT.cpp:247-273 needs the light's surface, radiance and light_density)
+MI_DEV void rec_store_dir(float4* base, const LSample& b) {
+  LVert t; t.surface = b.surface; t.omega = F3(0, 0, 0); t.throughput = b.radiance; t.a = b.light_density; t.A = b.area_density; t.finite = 1;
+  rec_store_l(base, t);
+}
+MI_DEV LSample rec_load_dir(const float4* base) {
+  const LVert t = rec_load_l(base);
+  LSample b; b.surface = t.surface; b.radiance = t.throughput; b.light_density = t.a; b.area_density = t.A; b.directional = true;
+  return b;
+}
+
+struct Lane { uint32_t px, py, fl; uint64_t sample; bool ok; };
+template <bool LIST>
+MI_DEV Lane lane_decode(const RenderParams& p, const BptState& w, uint32_t i) {
+  Lane l; l.px = l.py = l.fl = 0; l.sample = 0; l.ok = false;
+  if (LIST) {
+    const uint64_t item = w.first + i;
+    l.ok = i < w.lanes && item < p.list_n;
+    if (l.ok) { l.px = p.list_xy[2 * item]; l.py = p.list_xy[2 * item + 1]; l.sample = p.list_sample[item]; }
+  } else {
+    const uint32_t per_frame = p.tiles_x * p.tiles_y * 64u;
+    const uint32_t gi = w.first + i;
+    l.fl = gi / per_frame;
+    const uint32_t rem = gi - l.fl * per_frame, tile = rem >> 6, pix = rem & 63u;
+    const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    l.px = p.win_x0 + tx * 8u + (pix & 7u); l.py = p.win_y0 + ty * 8u + (pix >> 3);
+    l.sample = p.sample_offset + w.frame + l.fl;
+    l.ok = i < w.lanes && l.fl < w.frames && l.px < p.win_x0 + p.win_w && l.py < p.win_y0 + p.win_h;
+  }
+  return l;
+}
+MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, TravStack* stack) {
+  c.sb = p.sv.blob; c.sv = &p.sv; c.stack = stack;
+  c.beta = p.beta; c.roulette = p.roulette; c.rinv = 1.0f / p.roulette;
+  c.sphere_c = F3(w.sphere[0], w.sphere[1], w.sphere[2]); c.sphere_r = w.sphere[3];
+  c.n_basic = 0; c.n_shadow = 0;
+}
+
+}  // namespace
+
+// ---- stage A ----
+template <bool LIST, int QN>
+__global__ __launch_bounds__(kBlock, 4) void bpt_trace(const RenderParams p, const BptState w) {
+  extern __shared__ float4 smem[];
+  TravStack stack;
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
+  stack.cap = p.stack_entries;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const Lane ln = lane_decode<LIST>(p, w, i);
+  bool overflow = false;
+  if (i < w.lanes) {
+    uint32_t L = 0, E = 0, n_items = 0, n_em = 0, n_dir = 0, basic = 0;
+    if (ln.ok) {
+      Ctx c; ctx_init(c, p, w, &stack);
+      const m33 v2w = {F3(p.v2w[0], p.v2w[1], p.v2w[2]), F3(p.v2w[3], p.v2w[4], p.v2w[5]), F3(p.v2w[6], p.v2w[7], p.v2w[8])};
+      Surf cs;  // Technique::_camera_surface (Technique.cpp:107-116)
+      cs.position = F3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+      cs.tangent.c0 = v2w.c1; cs.tangent.c1 = -v2w.c2; cs.tangent.c2 = v2w.c0;
+      cs.material_id = (0u << 2) | MI_ENTITY_CAMERA;
+      cs.gnormal = -v2w.c2;
+      Rng g = rng_seed(p.seed, ln.py * p.width + ln.px, ln.sample);
+      const float u0 = rng_f(g), u1 = rng_f(g);
+      const float fx = float(ln.px) + u0, fy = float(ln.py) + u1;
+      const float vx = fx * p.res_y_inv * 2.0f - p.res_x * p.res_y_inv;
+      const float vy = fy * p.res_y_inv * 2.0f - 1.0f;
+      const f3 dir = mulmv(v2w, normalize(F3(vx, vy, -p.focal_length_y)));
+      float4* lrec = w.lslab + size_t(i) * w.max_vertices * 7u;
+      float4* erec = w.eslab + size_t(i) * w.max_vertices * 7u;
+      float4* nrec = w.nslab + size_t(i) * w.max_vertices * 7u;
+      float4* em = w.emission + size_t(i) * w.max_vertices;  // emission terms (eye sub-path hits on emitters): as many as vertices
+      if (!bpt_roulette(c, g)) {  // BPT.cpp:17-19
+        // ---- _traceLight (BPT.cpp:121-190) ----
+        if (!bpt_roulette(c, g)) {
+          const LSample ls = light_sample(c, g);
+          LVert prev = sample_to_vertex(c, ls);
+          uint32_t size = 1, prv = 0;
+          while (!bpt_roulette(c, g)) {
+            const BSample b = bpt_bsdf_sample(c, g, prev.surface, prev.omega);
+            const Surf surface = scene_intersect<QN>(c, prev.surface, b.omega, 1u << MI_ENTITY_MESH);
+            if (surface.material_id == 0xFFFFFFFFu) break;
+            if (size >= w.max_vertices) { overflow = true; break; }
+            LVert cur;
+            cur.surface = surface;
+            cur.omega = -b.omega;
+            const Edge e = make_edge(prev.surface, cur.surface, cur.omega);
+            cur.throughput = ((prev.throughput * b.q.throughput) * e.bCos) * c.rinv;
+            if (l1norm(cur.throughput) < MI_FLT_EPSILON) break;
+            cur.throughput = cur.throughput / b.q.density;
+            prev.finite = prev.finite < b.q.finite ? prev.finite : b.q.finite;
+            cur.finite = b.q.finite;
+            cur.a = 1.0f / betaf(c, e.fG * b.q.density);
+            cur.A = (prev.A * betaf(c, b.q.densityRev) + prev.a * float(prev.finite)) * betaf(c, e.bG) * cur.a;
+            if (b.q.finite == 0) { prev = cur; }
+            else { rec_store_l(lrec + size_t(prv) * 7u, prev); prev = cur; prv = size; ++size; }
+          }
+          const BSample last = bpt_bsdf_sample(c, g, prev.surface, prev.omega);
+          if (last.q.finite == 0) --size; else rec_store_l(lrec + size_t(prv) * 7u, prev);
+          L = size;
+        }
+        // ---- _traceEye without the connections (BPT.cpp:24-98) ----
+        EVert prev, cur;
+        Surf surface = cs;
+        prev.surface = surface; prev.omega = -dir; prev.throughput = F3(1, 1, 1) * c.rinv;
+        prev.finite = 1; prev.c = 0.0f; prev.C = 0.0f;
+        for (;;) {
+          const bool at_camera = (prev.surface.material_id & 3u) == MI_ENTITY_CAMERA;
+          if (E >= w.max_vertices) { overflow = true; break; }
+          if (at_camera) {
+            rec_store_e(erec + size_t(E) * 7u, prev, 0u, 0u);  // items [0, L): the splats of _connect_eye
+            n_items = L;
+          } else {
+            uint32_t kind = 0;
+            if (!bpt_roulette(c, g)) {  // BPT.cpp:278-288
+              const LSample b = light_sample(c, g);
+              if (!b.directional) { kind = 1; rec_store_l(nrec + size_t(E) * 7u, sample_to_vertex(c, b)); }
+              else { kind = 2; rec_store_dir(nrec + size_t(E) * 7u, b); ++n_dir; }
+            }
+            rec_store_e(erec + size_t(E) * 7u, prev, kind, n_items);
+            n_items += (kind ? 1u : 0u) + (L > 1u ? L - 1u : 0u);
+          }
+          const uint32_t k = E;
+          ++E;
+          const BSample b = bpt_bsdf_sample(c, g, prev.surface, prev.omega);
+          bool ended = false;
+          for (;;) {
+            surface = scene_intersect<QN>(c, surface, b.omega, 0xFFFFFFFFu);
+            if (surface.material_id == 0xFFFFFFFFu) {
+              if (at_camera) n_em = 0;  // BPT.cpp:45-47: a miss from the camera vertex returns the sky gradient (zero), not the radiance gathered through emitters
+              ended = true; break;
+            }
+            cur.surface = surface; cur.omega = -b.omega;
+            const Edge e = make_edge(prev.surface, cur.surface, cur.omega);
+            cur.throughput = (prev.throughput * b.q.throughput) * e.bCos;
+            if (l1norm(cur.throughput) < MI_FLT_EPSILON) { ended = true; break; }
+            cur.throughput = cur.throughput / b.q.density;
+            prev.finite = prev.finite < b.q.finite ? prev.finite : b.q.finite;
+            cur.finite = b.q.finite;
+            cur.c = 1.0f / betaf(c, e.fG * b.q.density);
+            cur.C = (prev.C * betaf(c, b.q.densityRev) + prev.c * float(prev.finite)) * betaf(c, e.bG) * cur.c;
+            if (surf_is_light(surface)) {
+              const f3 t = bpt_connect_light(c, cur);
+              if (n_em >= w.max_vertices) { overflow = true; ended = true; break; }
+              em[n_em++] = make_float4(t.x, t.y, t.z, __uint_as_float(k));
+            } else break;
+          }
+          if (ended) break;
+          prev = cur;
+          if (bpt_roulette(c, g)) break;
+          prev.throughput = prev.throughput * c.rinv;
+        }
+      }
+      basic = c.n_basic;
+    }
+    w.info[2 * size_t(i)] = make_uint4(L, E, n_items, n_em);
+    w.info[2 * size_t(i) + 1] = make_uint4(basic, n_dir, (ln.py << 16) | ln.px, (ln.fl << 1) | (ln.ok ? 1u : 0u));
+    w.item_offset[i] = n_items;
+  }
+  uint32_t o = overflow ? 1u : 0u;
+  for (int k = 32; k > 0; k >>= 1) o += __shfl_xor(o, k, 64);
+  if (o && (threadIdx.x & 63u) == 0 && p.counters) atomicAdd(&p.counters[15], (unsigned long long)o);
+}
+
+// exclusive scan of the per-path item counts (w.lanes + 1 entries, the last receives the total): tiles of 2048 entries are
+// scanned by one workgroup each, their totals by a single workgroup, then added back
+constexpr uint32_t kScanTile = 2048;
+__global__ __launch_bounds__(256) void bpt_scan_tiles(uint32_t* __restrict__ data, uint32_t total, uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8u;
+  uint32_t v[8], s = 0;
+  for (int k = 0; k < 8; ++k) { v[k] = base + k < total ? data[base + k] : 0u; s += v[k]; }
+  uint32_t incl = s;  // inclusive scan of the per-thread sums over the wave, then over the four waves
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if ((tid & 63u) >= uint32_t(o)) incl += t; }
+  if ((tid & 63u) == 63u) wsum[tid >> 6] = incl;
+  __syncthreads();
+  uint32_t run = incl - s;
+  for (uint32_t w2 = 0; w2 < (tid >> 6); ++w2) run += wsum[w2];
+  for (int k = 0; k < 8; ++k) { if (base + k < total) data[base + k] = run; run += v[k]; }
+  if (tid == 255u) tile_sums[blockIdx.x] = run;
+}
+__global__ __launch_bounds__(1024) void bpt_scan_sums(uint32_t* __restrict__ sums, uint32_t n) {  // n <= 1024 * chunk
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x, chunk = (n + 1023u) / 1024u, b = tid * chunk, e = b + chunk < n ? b + chunk : n;
+  uint32_t s = 0;
+  for (uint32_t i = b; i < e; ++i) s += sums[i];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) { const uint32_t v = tid >= off ? part[tid - off] : 0u; __syncthreads(); part[tid] += v; __syncthreads(); }
+  uint32_t run = tid ? part[tid - 1] : 0u;
+  for (uint32_t i = b; i < e; ++i) { const uint32_t v = sums[i]; sums[i] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void bpt_scan_add(uint32_t* __restrict__ data, uint32_t total, const uint32_t* __restrict__ tile_sums) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < total) data[i] += tile_sums[i / kScanTile];
+}
+
+// ---- stage B: one lane per connection item ----
+template <bool LIST, int QN>
+__global__ __launch_bounds__(kBlock, 4) void bpt_items(const RenderParams p, const BptState w, uint32_t item_first, uint32_t item_count) {
+  extern __shared__ float4 smem[];
+  TravStack stack;
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
+  stack.cap = p.stack_entries;
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= item_count) return;
+  const uint32_t item = item_first + j;
+  // which path?  last path whose first item is <= item (paths without items share an offset with their successor)
+  uint32_t lo = 0, hi = w.lanes;
+  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (w.item_offset[mid] <= item) lo = mid; else hi = mid; }
+  const uint32_t path = lo;
+  const uint32_t local = item - w.item_offset[path];
+  const uint4 inf = w.info[2 * size_t(path)];
+  const uint32_t L = inf.x, E = inf.y;
+  const float4* lrec = w.lslab + size_t(path) * w.max_vertices * 7u;
+  const float4* erec = w.eslab + size_t(path) * w.max_vertices * 7u;
+  const float4* nrec = w.nslab + size_t(path) * w.max_vertices * 7u;
+  Ctx c; ctx_init(c, p, w, &stack);
+  f3 value = F3(0, 0, 0); uint32_t flags = 0;  // bit 0: a shadow ray was cast, bit 1: a closest-hit ray was cast, bit 2: splat inside the image
+  if (local < L) {
+    // ---- _connect_eye (BPT.cpp:295-321): light vertex `local` to the camera ----
+    uint32_t kind, item0;
+    const EVert eye = rec_load_e(erec, kind, item0);
+    const LVert lv = rec_load_l(lrec + size_t(local) * 7u);
+    const m33 w2v = {F3(w.w2v[0], w.w2v[1], w.w2v[2]), F3(w.w2v[3], w.w2v[4], w.w2v[5]), F3(w.w2v[6], w.w2v[7], w.w2v[8])};
+    const float focal_factor_y = p.focal_length_y * p.focal_length_y * 0.25f;
+    const f3 omega = normalize(lv.surface.position - eye.surface.position);
+    const f3 vd = mulmv(w2v, omega);
+    const float factor = p.focal_length_y / -vd.z;  // pixel_position (Cameras.cpp:134-144)
+    const float x = vd.x * factor, y = vd.y * factor;
+    const float py = (y + 1.0f) * p.res_y * 0.5f;
+    const float px = (x + p.res_x * p.res_y_inv) * p.res_y * 0.5f;
+    if (0 <= px && px < p.res_x && 0 <= py && py < p.res_y) {
+      const int ix = int(px), iy = int(py);
+      const f3 ln = lv.surface.tangent.c1, en = eye.surface.tangent.c1;
+      const float normal_coefficient = fabsf(dot(omega, lv.surface.gnormal) * dot(lv.omega, ln) / (dot(omega, ln) * dot(lv.omega, lv.surface.gnormal)));
+      const float ce = fabsf(dot(en, omega));
+      const float focal_coefficient = 1.0f / (ce * ce * ce);
+      value = (bpt_connect<QN>(c, lv, eye) * focal_factor_y) * (normal_coefficient * focal_coefficient);
+      flags = 1u | 4u;
+      if (!LIST) {
+        const uint32_t fl = w.info[2 * size_t(path) + 1].w >> 1;
+        double* l = w.light + 3 * (size_t(fl) * p.width * p.height + size_t(iy) * size_t(p.res_x) + size_t(ix));
+        atomicAdd(&l[0], double(value.x)); atomicAdd(&l[1], double(value.y)); atomicAdd(&l[2], double(value.z));
+      }
+    }
+  } else {
+    // which eye vertex?  last one (k >= 1) whose first item is <= local
+    uint32_t klo = 1, khi = E;
+    while (khi - klo > 1u) { const uint32_t mid = (klo + khi) >> 1; if (__float_as_uint(erec[size_t(mid) * 7u + 5u].w) <= local) klo = mid; else khi = mid; }
+    uint32_t kind, item0;
+    const EVert eye = rec_load_e(erec + size_t(klo) * 7u, kind, item0);
+    const uint32_t idx = local - item0;
+    if (kind != 0u && idx == 0u) {
+      if (kind == 1u) { const LVert lv = rec_load_l(nrec + size_t(klo) * 7u); value = bpt_connect<QN>(c, lv, eye); flags = 1u; }
+      else { const LSample b = rec_load_dir(nrec + size_t(klo) * 7u); value = bpt_connect_directional<QN>(c, eye, b); flags = 2u; }
+    } else {
+      const uint32_t li = idx - (kind ? 1u : 0u) + 1u;
+      const LVert lv = rec_load_l(lrec + size_t(li) * 7u);
+      value = bpt_connect<QN>(c, lv, eye); flags = 1u;
+    }
+  }
+  w.values[j] = make_float4(value.x, value.y, value.z, __uint_as_float(flags));
+}
+
+// ---- stage C: per path, the sums in the reference's order ----
+template <bool LIST>
+__global__ __launch_bounds__(256) void bpt_gather(const RenderParams p, const BptState w, uint32_t item_first) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  uint32_t nb = 0, ns = 0, np = 0;
+  if (i < w.lanes) {
+    const uint4 inf = w.info[2 * size_t(i)], inf2 = w.info[2 * size_t(i) + 1];
+    if (inf2.w & 1u) {
+      const uint32_t L = inf.x, E = inf.y, n_em = inf.w;
+      const float4* vals = w.values + (size_t(w.item_offset[i]) - item_first);
+      const float4* erec = w.eslab + size_t(i) * w.max_vertices * 7u;
+      const float4* em = w.emission + size_t(i) * w.max_vertices;  // emission terms (eye sub-path hits on emitters): as many as vertices
+      f3 radiance = F3(0, 0, 0), splat_sum = F3(0, 0, 0);
+      uint32_t n_splat = 0, shadow = 0, basic = inf2.x, m = 0;
+      if (E > 0u) for (uint32_t s = 0; s < L; ++s) {
+        const float4 v = vals[s]; const uint32_t f = __float_as_uint(v.w);
+        if (f & 4u) { splat_sum = splat_sum + F3(v.x, v.y, v.z); ++n_splat; ++shadow; }
+      }
+      for (uint32_t k = 0; k < E; ++k) {
+        if (k >= 1u) {
+          const uint32_t kind = __float_as_uint(erec[size_t(k) * 7u + 4u].w), item0 = __float_as_uint(erec[size_t(k) * 7u + 5u].w);
+          const uint32_t n_k = (kind ? 1u : 0u) + (L > 1u ? L - 1u : 0u);
+          f3 local = F3(0, 0, 0);  // BPT.cpp:276: a vertex's connections are summed on their own, then added to the path's radiance
+          for (uint32_t t = 0; t < n_k; ++t) {
+            const float4 v = vals[item0 + t]; const uint32_t f = __float_as_uint(v.w);
+            local = local + F3(v.x, v.y, v.z);
+            shadow += f & 1u; basic += (f >> 1) & 1u;
+          }
+          radiance = radiance + local;
+        }
+        while (m < n_em && __float_as_uint(em[m].w) == k) { radiance = radiance + F3(em[m].x, em[m].y, em[m].z); ++m; }
+      }
+      nb = basic; ns = shadow; np = 1;
+      if (LIST) {
+        const size_t item = size_t(w.first) + i;
+        p.list_radiance[3 * item] = radiance.x; p.list_radiance[3 * item + 1] = radiance.y; p.list_radiance[3 * item + 2] = radiance.z;
+        w.list_splat_sum[3 * item] = splat_sum.x; w.list_splat_sum[3 * item + 1] = splat_sum.y; w.list_splat_sum[3 * item + 2] = splat_sum.z;
+        w.list_counts3[3 * item] = basic; w.list_counts3[3 * item + 1] = shadow; w.list_counts3[3 * item + 2] = n_splat;
+      } else {
+        const uint32_t px = inf2.z & 0xFFFFu, py = inf2.z >> 16, fl = inf2.w >> 1;
+        float* e = w.eye + 3 * (size_t(fl) * p.width * p.height + size_t(py) * p.width + px);
+        e[0] = radiance.x; e[1] = radiance.y; e[2] = radiance.z;
+      }
+    }
+  }
+  for (int k = 32; k > 0; k >>= 1) { nb += __shfl_xor(nb, k, 64); ns += __shfl_xor(ns, k, 64); np += __shfl_xor(np, k, 64); }
+  if ((threadIdx.x & 63u) == 0 && p.counters) {
+    if (nb) atomicAdd(&p.counters[0], (unsigned long long)nb);
+    if (ns) atomicAdd(&p.counters[1], (unsigned long long)ns);
+    if (np) atomicAdd(&p.counters[3], (unsigned long long)np);
+  }
+}
+
+namespace {
 }  // namespace
 
 // one lane = one (pixel, sample): shoot() + _traceEye (Technique.cpp:321-338)
@@ -472,6 +836,38 @@ hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list,
   const dim3 grid((w.lanes + kBlock - 1) / kBlock), block(kBlock);
   if (list) { if (p.wide_nodes) hipLaunchKernelGGL((bpt_frame<true, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_frame<true, 1>), grid, block, lds, stream, p, w); }
   else { if (p.wide_nodes) hipLaunchKernelGGL((bpt_frame<false, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_frame<false, 1>), grid, block, lds, stream, p, w); }
+  return hipGetLastError();
+}
+// staged form: trace + scan (returns the number of connection items of the launch's paths), then items + gather
+hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, hipStream_t stream, uint32_t* total_items) {
+  const size_t lds = size_t(p.stack_entries) * kBlock * 4;
+  const dim3 grid((w.lanes + kBlock - 1) / kBlock), block(kBlock);
+  hipError_t e = hipMemsetAsync(w.item_offset + w.lanes, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  if (list) { if (p.wide_nodes) hipLaunchKernelGGL((bpt_trace<true, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_trace<true, 1>), grid, block, lds, stream, p, w); }
+  else { if (p.wide_nodes) hipLaunchKernelGGL((bpt_trace<false, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_trace<false, 1>), grid, block, lds, stream, p, w); }
+  {
+    const uint32_t total = w.lanes + 1u, tiles = (total + kScanTile - 1u) / kScanTile;
+    hipLaunchKernelGGL(bpt_scan_tiles, dim3(tiles), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);
+    hipLaunchKernelGGL(bpt_scan_sums, dim3(1), dim3(1024), 0, stream, w.scan_tmp, tiles);
+    hipLaunchKernelGGL(bpt_scan_add, dim3((total + 255u) / 256u), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);
+  }
+  e = hipMemcpyAsync(total_items, w.item_offset + w.lanes, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, uint32_t total_items, hipStream_t stream) {
+  const size_t lds = size_t(p.stack_entries) * kBlock * 4;
+  if (total_items) {
+    const dim3 grid((total_items + kBlock - 1) / kBlock), block(kBlock);
+    if (list) { if (p.wide_nodes) hipLaunchKernelGGL((bpt_items<true, 2>), grid, block, lds, stream, p, w, 0u, total_items); else hipLaunchKernelGGL((bpt_items<true, 1>), grid, block, lds, stream, p, w, 0u, total_items); }
+    else { if (p.wide_nodes) hipLaunchKernelGGL((bpt_items<false, 2>), grid, block, lds, stream, p, w, 0u, total_items); else hipLaunchKernelGGL((bpt_items<false, 1>), grid, block, lds, stream, p, w, 0u, total_items); }
+  }
+  const dim3 g2((w.lanes + 255u) / 256u);
+  if (list) hipLaunchKernelGGL(bpt_gather<true>, g2, dim3(256), 0, stream, p, w, 0u);
+  else hipLaunchKernelGGL(bpt_gather<false>, g2, dim3(256), 0, stream, p, w, 0u);
   return hipGetLastError();
 }
 hipError_t bpt_launch_commit(const RenderParams& p, const BptState& w, hipStream_t stream) {

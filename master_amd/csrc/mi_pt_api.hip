@@ -50,6 +50,8 @@ struct mi_pt_handle {
   uint32_t wf_iterations = 0;
   // BPT: light sub-path slab, eye / light images of a frame
   float4* bpt_slab = nullptr; size_t bpt_slab_bytes = 0;
+  char* bpt_arena = nullptr; size_t bpt_arena_bytes = 0;      // staged form: slabs, emission terms, path info, item offsets
+  float4* bpt_values = nullptr; size_t bpt_values_bytes = 0;  // staged form: connection item values
   float* bpt_eye = nullptr; size_t bpt_eye_bytes = 0;
   double* bpt_light = nullptr; size_t bpt_light_bytes = 0;
   float sphere[4] = {0, 0, 0, 0};
@@ -324,6 +326,8 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->partial) hipFree(h->partial);
   if (h->wf_arena) hipFree(h->wf_arena);
   if (h->bpt_slab) hipFree(h->bpt_slab);
+  if (h->bpt_arena) hipFree(h->bpt_arena);
+  if (h->bpt_values) hipFree(h->bpt_values);
   if (h->bpt_eye) hipFree(h->bpt_eye);
   if (h->bpt_light) hipFree(h->bpt_light);
   if (h->d_rgbn) hipFree(h->d_rgbn);
@@ -546,6 +550,21 @@ int mi_pt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint3
 }
 
 namespace {
+bool bpt_staged() {  // MI_BPT_STAGED=0 selects the one-kernel form (kept for A/B)
+  const char* e = std::getenv("MI_BPT_STAGED");
+  return !(e && std::atoi(e) == 0);
+}
+// one launch of `w.lanes` paths: the one-kernel form, or trace -> (item count) -> items -> gather
+int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool list, hipStream_t stream) {
+  if (!bpt_staged()) { HIP_TRY(mi::bpt_launch_frame(p, w, list, stream)); return MI_OK; }
+  uint32_t total = 0;
+  HIP_TRY(mi::bpt_stage_trace(p, w, list, stream, &total));
+  int rc = ensure(reinterpret_cast<void**>(&h->bpt_values), &h->bpt_values_bytes, size_t(total ? total : 1) * 16);
+  if (rc) return rc;
+  w.values = h->bpt_values;
+  HIP_TRY(mi::bpt_stage_connect(p, w, list, total, stream));
+  return MI_OK;
+}
 // buffers and per-launch constants shared by the two BPT entry points
 int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint64_t total_lanes, mi::RenderParams& p, mi::BptState& w,
                 uint32_t* lanes_per_launch) {
@@ -561,12 +580,28 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   std::memcpy(w.sphere, h->sphere, sizeof w.sphere);
   uint64_t lanes = total_lanes < (1ull << 20) ? total_lanes : (1ull << 20);  // up to 1 M paths per launch
   lanes = (lanes + 255) / 256 * 256;
-  uint64_t cap = (24ull << 30) / (lanes * 112ull);  // light sub-path slab: up to 24 GB of the 288 GB
+  const bool staged = bpt_staged();
+  uint64_t cap = (staged ? (16ull << 30) : (24ull << 30)) / (lanes * 112ull);  // vertex slabs: 3 x 16 GB (staged) or 24 GB of the 288 GB
   if (cap > 1024) cap = 1024;
   if (cap < 64) cap = 64;
-  rc = ensure(reinterpret_cast<void**>(&h->bpt_slab), &h->bpt_slab_bytes, size_t(lanes) * cap * 112);
-  if (rc) return rc;
-  w.slab = h->bpt_slab; w.max_vertices = uint32_t(cap);
+  w.max_vertices = uint32_t(cap);
+  if (staged) {
+    const size_t slab = size_t(lanes) * cap * 112;
+    const size_t need = 3 * slab + size_t(lanes) * (cap * 16 + 32 + 4 + 1) + 8192;
+    rc = ensure(reinterpret_cast<void**>(&h->bpt_arena), &h->bpt_arena_bytes, need);
+    if (rc) return rc;
+    char* a = h->bpt_arena;
+    auto take = [&](size_t bytes) { char* r = a; a += (bytes + 255) / 256 * 256; return r; };
+    w.lslab = reinterpret_cast<float4*>(take(slab)); w.eslab = reinterpret_cast<float4*>(take(slab)); w.nslab = reinterpret_cast<float4*>(take(slab));
+    w.emission = reinterpret_cast<float4*>(take(size_t(lanes) * cap * 16));
+    w.info = reinterpret_cast<uint4*>(take(size_t(lanes) * 32));
+    w.item_offset = reinterpret_cast<uint32_t*>(take((size_t(lanes) + 1) * 4));
+    w.scan_tmp = reinterpret_cast<uint32_t*>(take((size_t(lanes) / 2048 + 2) * 4));
+  } else {
+    rc = ensure(reinterpret_cast<void**>(&h->bpt_slab), &h->bpt_slab_bytes, size_t(lanes) * cap * 112);
+    if (rc) return rc;
+    w.slab = h->bpt_slab;
+  }
   *lanes_per_launch = uint32_t(lanes);
   p.counters = h->d_counters;
   return MI_OK;
@@ -606,7 +641,8 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
     const uint64_t lanes_total = total * w.frames;
     for (uint64_t first = 0; first < lanes_total; first += per_launch) {
       w.first = uint32_t(first); w.lanes = uint32_t(lanes_total - first < per_launch ? lanes_total - first : per_launch);
-      HIP_TRY(mi::bpt_launch_frame(p, w, false, stream));
+      rc = bpt_launch(h, p, w, false, stream);
+      if (rc) return rc;
     }
     HIP_TRY(mi::bpt_launch_commit(p, w, stream));
   }
@@ -652,7 +688,8 @@ int mi_bpt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), h->stream));
   for (uint64_t first = 0; first < n; first += per_launch) {
     w.first = uint32_t(first); w.lanes = uint32_t(n - first < per_launch ? n - first : per_launch);
-    HIP_TRY(mi::bpt_launch_frame(p, w, true, h->stream));
+    rc = bpt_launch(h, p, w, true, h->stream);
+    if (rc) return rc;
   }
   unsigned long long c[24];
   HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, h->stream));

@@ -84,6 +84,24 @@ def test_bpt_and_pt_converge_to_the_same_image(cornell):
     assert np.sqrt(np.mean((br - pr) ** 2)) < 0.05
 
 
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "MirrorAndAreaLight", "TestCaseFurnace", "TestCase10"])
+def test_bpt_one_kernel_form_equals_staged_form(monkeypatch, name):
+    """MI_BPT_STAGED=0 runs the whole path in one lane; the staged default cuts it into trace / items / gather.  Same terms,
+    same order of every float sum: identical bits."""
+    s = load_scene(name)
+    pt = ma.PathTracing(s, beta=2.0)
+    xy, si = _paths(64, 48, 8000, 11)
+    a = pt.bpt_trace_paths(64, 48, xy, si, seed=5)
+    monkeypatch.setenv("MI_BPT_STAGED", "0")
+    b = pt.bpt_trace_paths(64, 48, xy, si, seed=5)
+    assert np.array_equal(a[2], b[2]) and _bits_equal(a[0], b[0]).all() and _bits_equal(a[1], b[1]).all()
+    img_b = pt.bpt_render_rgbn(40, 30, spp=6, seed=2)
+    monkeypatch.delenv("MI_BPT_STAGED")
+    img_a = pt.bpt_render_rgbn(40, 30, spp=6, seed=2)
+    assert np.array_equal(img_a[..., 3], img_b[..., 3])
+    np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)
+
+
 def test_bpt_error_behaviour(cornell):
     pt = ma.PathTracing(cornell)
     with pytest.raises(ma.MiError):

@@ -29,8 +29,8 @@ struct BptState {
 };
 
 hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list, hipStream_t stream);
-hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, hipStream_t stream, uint32_t* total_items);
-hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, uint32_t total_items, hipStream_t stream);
+hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, bool lds_scene, hipStream_t stream, uint32_t* total_items);
+hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, bool lds_scene, uint32_t total_items, hipStream_t stream);
 hipError_t bpt_launch_commit(const RenderParams& p, const BptState& w, hipStream_t stream);
 
 }  // namespace mi

@@ -128,15 +128,15 @@ template <int QN>
 MI_DEV Surf scene_intersect(Ctx& c, const Surf& from, f3 dir, uint32_t mask) {
   const f3 org = nudge(from.position, from.gnormal, dir);
   Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-  traverse<false, false, QN>(c.sb, *c.sv, *c.stack, org, dir, mask, h);
+  traverse<false, false, QN, QN == 0 ? 5 : 4>(c.sb, *c.sv, *c.stack, org, dir, mask, h);  // QN == 0: padded LDS copy of the scene
   ++c.n_basic;
   if (h.id == 0xFFFFFFFFu) { Surf s; s.position = F3(0, 0, 0); s.gnormal = F3(0, 0, 0); s.tangent.c0 = s.tangent.c1 = s.tangent.c2 = F3(0, 0, 0); s.material_id = 0xFFFFFFFFu; return s; }
-  return query_surface(c.sb, *c.sv, org, dir, h);
+  return query_surface<QN == 0 ? 9 : 8>(c.sb, *c.sv, org, dir, h);
 }
 template <int QN>
 MI_DEV float scene_occluded(Ctx& c, const Surf& origin, const Surf& target) {
   ++c.n_shadow;
-  return occluded<false, QN>(c.sb, *c.sv, *c.stack, origin.position, origin.gnormal, target.position, target.gnormal);
+  return occluded<false, QN, QN == 0 ? 5 : 4>(c.sb, *c.sv, *c.stack, origin.position, origin.gnormal, target.position, target.gnormal);
 }
 
 // AreaLights::sample (AreaLights.cpp:121-140)
@@ -445,8 +445,8 @@ MI_DEV Lane lane_decode(const RenderParams& p, const BptState& w, uint32_t i) {
   }
   return l;
 }
-MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, TravStack* stack) {
-  c.sb = p.sv.blob; c.sv = &p.sv; c.stack = stack;
+MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, TravStack* stack, const float4* sb, const SceneView* sv) {
+  c.sb = sb; c.sv = sv; c.stack = stack;
   c.beta = p.beta; c.roulette = p.roulette; c.rinv = 1.0f / p.roulette;
   c.sphere_c = F3(w.sphere[0], w.sphere[1], w.sphere[2]); c.sphere_r = w.sphere[3];
   c.n_basic = 0; c.n_shadow = 0;
@@ -458,8 +458,12 @@ MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, TravStack
 template <bool LIST, int QN>
 __global__ __launch_bounds__(kBlock, 4) void bpt_trace(const RenderParams p, const BptState w) {
   extern __shared__ float4 smem[];
+  SceneView sv = p.sv;
+  const float4* sb = sv.blob;
+  uint32_t scene_f4 = 0;
+  if (QN == 0) { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); sb = smem; __syncthreads(); }
   TravStack stack;
-  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
   stack.cap = p.stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const Lane ln = lane_decode<LIST>(p, w, i);
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(kBlock, 4) void bpt_trace(const RenderParams p, con
   if (i < w.lanes) {
     uint32_t L = 0, E = 0, n_items = 0, n_em = 0, n_dir = 0, basic = 0;
     if (ln.ok) {
-      Ctx c; ctx_init(c, p, w, &stack);
+      Ctx c; ctx_init(c, p, w, &stack, sb, &sv);
       const m33 v2w = {F3(p.v2w[0], p.v2w[1], p.v2w[2]), F3(p.v2w[3], p.v2w[4], p.v2w[5]), F3(p.v2w[6], p.v2w[7], p.v2w[8])};
       Surf cs;  // Technique::_camera_surface (Technique.cpp:107-116)
       cs.position = F3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
@@ -613,8 +617,12 @@ __global__ __launch_bounds__(256) void bpt_scan_add(uint32_t* __restrict__ data,
 template <bool LIST, int QN>
 __global__ __launch_bounds__(kBlock, 4) void bpt_items(const RenderParams p, const BptState w, uint32_t item_first, uint32_t item_count) {
   extern __shared__ float4 smem[];
+  SceneView sv = p.sv;
+  const float4* sb = sv.blob;
+  uint32_t scene_f4 = 0;
+  if (QN == 0) { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); sb = smem; __syncthreads(); }
   TravStack stack;
-  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
   stack.cap = p.stack_entries;
   const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= item_count) return;
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(kBlock, 4) void bpt_items(const RenderParams p, con
   const float4* lrec = w.lslab + size_t(path) * w.max_vertices * 7u;
   const float4* erec = w.eslab + size_t(path) * w.max_vertices * 7u;
   const float4* nrec = w.nslab + size_t(path) * w.max_vertices * 7u;
-  Ctx c; ctx_init(c, p, w, &stack);
+  Ctx c; ctx_init(c, p, w, &stack, sb, &sv);
   f3 value = F3(0, 0, 0); uint32_t flags = 0;  // bit 0: a shadow ray was cast, bit 1: a closest-hit ray was cast, bit 2: splat inside the image
   if (local < L) {
     // ---- _connect_eye (BPT.cpp:295-321): light vertex `local` to the camera ----
@@ -839,13 +847,18 @@ hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list,
   return hipGetLastError();
 }
 // staged form: trace + scan (returns the number of connection items of the launch's paths), then items + gather
-hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, hipStream_t stream, uint32_t* total_items) {
-  const size_t lds = size_t(p.stack_entries) * kBlock * 4;
+hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, bool lds_scene, hipStream_t stream, uint32_t* total_items) {
+  const size_t lds = size_t(p.stack_entries) * kBlock * 4 + (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0);
   const dim3 grid((w.lanes + kBlock - 1) / kBlock), block(kBlock);
   hipError_t e = hipMemsetAsync(w.item_offset + w.lanes, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
-  if (list) { if (p.wide_nodes) hipLaunchKernelGGL((bpt_trace<true, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_trace<true, 1>), grid, block, lds, stream, p, w); }
-  else { if (p.wide_nodes) hipLaunchKernelGGL((bpt_trace<false, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_trace<false, 1>), grid, block, lds, stream, p, w); }
+  void (*fn)(const RenderParams, const BptState) = nullptr;
+  if (lds_scene) fn = list ? bpt_trace<true, 0> : bpt_trace<false, 0>;
+  else if (p.wide_nodes) fn = list ? bpt_trace<true, 2> : bpt_trace<false, 2>;
+  else fn = list ? bpt_trace<true, 1> : bpt_trace<false, 1>;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, grid, block, lds, stream, p, w);
   {
     const uint32_t total = w.lanes + 1u, tiles = (total + kScanTile - 1u) / kScanTile;
     hipLaunchKernelGGL(bpt_scan_tiles, dim3(tiles), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);
@@ -858,12 +871,17 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
   if (e != hipSuccess) return e;
   return hipGetLastError();
 }
-hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, uint32_t total_items, hipStream_t stream) {
-  const size_t lds = size_t(p.stack_entries) * kBlock * 4;
+hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, bool lds_scene, uint32_t total_items, hipStream_t stream) {
+  const size_t lds = size_t(p.stack_entries) * kBlock * 4 + (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0);
   if (total_items) {
     const dim3 grid((total_items + kBlock - 1) / kBlock), block(kBlock);
-    if (list) { if (p.wide_nodes) hipLaunchKernelGGL((bpt_items<true, 2>), grid, block, lds, stream, p, w, 0u, total_items); else hipLaunchKernelGGL((bpt_items<true, 1>), grid, block, lds, stream, p, w, 0u, total_items); }
-    else { if (p.wide_nodes) hipLaunchKernelGGL((bpt_items<false, 2>), grid, block, lds, stream, p, w, 0u, total_items); else hipLaunchKernelGGL((bpt_items<false, 1>), grid, block, lds, stream, p, w, 0u, total_items); }
+    void (*fn)(const RenderParams, const BptState, uint32_t, uint32_t) = nullptr;
+    if (lds_scene) fn = list ? bpt_items<true, 0> : bpt_items<false, 0>;
+    else if (p.wide_nodes) fn = list ? bpt_items<true, 2> : bpt_items<false, 2>;
+    else fn = list ? bpt_items<true, 1> : bpt_items<false, 1>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, grid, block, lds, stream, p, w, 0u, total_items);
   }
   const dim3 g2((w.lanes + 255u) / 256u);
   if (list) hipLaunchKernelGGL(bpt_gather<true>, g2, dim3(256), 0, stream, p, w, 0u);

@@ -58,6 +58,20 @@ MI_DEV bool tri_test(const float4* __restrict__ tris, uint32_t pos, f3 org, f3 d
   return false;
 }
 
+// LDS copy of the scene blob with padded records (nodes 64 -> 80 B, shading records 128 -> 144 B: power-of-two strides put the same
+// field of every record into the same few banks).  Every thread of the workgroup calls this; `sv` is rewritten to the LDS layout
+// (strides 5 / 9 float4: traverse<.., NS = 5>, query_surface<9>).  The caller synchronises the workgroup afterwards.
+MI_DEV uint32_t lds_scene_f4(const SceneView& sv) { return sv.blob_f4 + sv.n_nodes + sv.n_tris; }
+MI_DEV void stage_scene_to_lds(float4* __restrict__ smem, SceneView& sv, uint32_t tid) {
+  const uint32_t o_tris = sv.n_nodes * 5u, o_shade = o_tris + sv.n_tris * 3u, o_rest = o_shade + sv.n_tris * 9u;
+  for (uint32_t i = tid; i < sv.n_nodes * 4u; i += kBlock) smem[(i >> 2) * 5u + (i & 3u)] = sv.blob[sv.off_nodes + i];
+  for (uint32_t i = tid; i < sv.n_tris * 3u; i += kBlock) smem[o_tris + i] = sv.blob[sv.off_tris + i];
+  for (uint32_t i = tid; i < sv.n_tris * 8u; i += kBlock) smem[o_shade + (i >> 3) * 9u + (i & 7u)] = sv.blob[sv.off_shade + i];
+  for (uint32_t i = tid; i < sv.blob_f4 - sv.off_mats; i += kBlock) smem[o_rest + i] = sv.blob[sv.off_mats + i];
+  sv.off_lights = o_rest + (sv.off_lights - sv.off_mats); sv.off_cdf = o_rest + (sv.off_cdf - sv.off_mats);
+  sv.off_nodes = 0u; sv.off_tris = o_tris; sv.off_shade = o_shade; sv.off_mats = o_rest;
+}
+
 // Slab test.  Not part of the bit-exact contract: it only has to be conservative (leaf boxes are
 // padded, the interval is widened), because the closest hit is chosen by (t, id) and does not
 // depend on which boxes were opened.  t = lo * inv - org * inv is one fma per plane; its absolute
@@ -251,14 +265,14 @@ MI_DEV f3 nudge(f3 position, f3 gnormal, f3 dir) {
 }
 
 // Scene::occluded (Scene.cpp:151-180): 1 = visible.
-template <bool COUNT = false, int QUANT = 0>
+template <bool COUNT = false, int QUANT = 0, int NS = 4>
 MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 opos, f3 ognormal, f3 tpos,
                       f3 tgnormal, Visits* vis = nullptr) {
   const f3 direction = tpos - opos;  // Scene.cpp:153 normalises; only signs are used
   const f3 ao = opos + (ognormal * (dot(ognormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   const f3 at = tpos + (tgnormal * (dot(tgnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   Hit h; h.t = 1.0f; h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-  traverse<true, COUNT, QUANT>(sb, sv, stack, ao, at - ao, 1u << MI_ENTITY_MESH, h, vis);
+  traverse<true, COUNT, QUANT, NS>(sb, sv, stack, ao, at - ao, 1u << MI_ENTITY_MESH, h, vis);
   return h.id != 0xFFFFFFFFu ? 0.f : 1.f;
 }
 

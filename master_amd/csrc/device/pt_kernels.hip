@@ -68,21 +68,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps everything derived from it in SGPRs
   SceneView sv = p.sv;
 
-  // LDS copy of the scene blob with padded records (nodes 64 -> 80 B, shading records 128 -> 144 B): power-of-two strides
-  // put the same field of every record into the same few banks
+  // LDS-resident variant: padded copy of the scene blob (stage_scene_to_lds, pt_device.h)
   constexpr int NS = LDS_SCENE ? 5 : 4, SS = LDS_SCENE ? 9 : 8;
-  const uint32_t blob_f4 = LDS_SCENE ? sv.blob_f4 + sv.n_nodes + sv.n_tris : 0u;
+  const uint32_t blob_f4 = LDS_SCENE ? lds_scene_f4(sv) : 0u;
   const float4* sb = sv.blob;
-  if (LDS_SCENE) {
-    const uint32_t o_tris = sv.n_nodes * 5u, o_shade = o_tris + sv.n_tris * 3u, o_rest = o_shade + sv.n_tris * 9u;
-    for (uint32_t i = tid; i < sv.n_nodes * 4u; i += kBlock) smem[(i >> 2) * 5u + (i & 3u)] = sv.blob[sv.off_nodes + i];
-    for (uint32_t i = tid; i < sv.n_tris * 3u; i += kBlock) smem[o_tris + i] = sv.blob[sv.off_tris + i];
-    for (uint32_t i = tid; i < sv.n_tris * 8u; i += kBlock) smem[o_shade + (i >> 3) * 9u + (i & 7u)] = sv.blob[sv.off_shade + i];
-    for (uint32_t i = tid; i < sv.blob_f4 - sv.off_mats; i += kBlock) smem[o_rest + i] = sv.blob[sv.off_mats + i];
-    sv.off_lights = o_rest + (sv.off_lights - sv.off_mats); sv.off_cdf = o_rest + (sv.off_cdf - sv.off_mats);
-    sv.off_nodes = 0u; sv.off_tris = o_tris; sv.off_shade = o_shade; sv.off_mats = o_rest;
-    sb = smem;
-  }
+  if (LDS_SCENE) { stage_scene_to_lds(smem, sv, tid); sb = smem; }
   TravStack stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + blob_f4) + tid);
   stack.cap = p.stack_entries;

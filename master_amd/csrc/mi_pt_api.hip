@@ -558,11 +558,12 @@ bool bpt_staged() {  // MI_BPT_STAGED=0 selects the one-kernel form (kept for A/
 int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool list, hipStream_t stream) {
   if (!bpt_staged()) { HIP_TRY(mi::bpt_launch_frame(p, w, list, stream)); return MI_OK; }
   uint32_t total = 0;
-  HIP_TRY(mi::bpt_stage_trace(p, w, list, stream, &total));
+  const bool lds = use_lds_scene(h);  // small scenes: padded copy of the blob in LDS, binary walk
+  HIP_TRY(mi::bpt_stage_trace(p, w, list, lds, stream, &total));
   int rc = ensure(reinterpret_cast<void**>(&h->bpt_values), &h->bpt_values_bytes, size_t(total ? total : 1) * 16);
   if (rc) return rc;
   w.values = h->bpt_values;
-  HIP_TRY(mi::bpt_stage_connect(p, w, list, total, stream));
+  HIP_TRY(mi::bpt_stage_connect(p, w, list, lds, total, stream));
   return MI_OK;
 }
 // buffers and per-launch constants shared by the two BPT entry points
@@ -572,7 +573,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   int rc = fill_camera(h, camera_id, width, height, p);
   if (rc) return rc;
   fill_pt(h, p);
-  p.stack_entries = h->stack_entries_hbm;  // the BPT kernels read the scene from HBM
+  p.stack_entries = (bpt_staged() && use_lds_scene(h)) ? h->info.stack_entries : h->stack_entries_hbm;  // staged kernels stage small scenes into LDS
   mi_camera_frame fr;
   rc = mi_camera_setup(&h->scene.cameras[camera_id], float(width) / float(height), &fr);
   if (rc) return rc;

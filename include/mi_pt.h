@@ -261,12 +261,13 @@ typedef struct mi_bvh_info {
  * on the same handle: roulette and beta come from mi_pt_params (beta 0, 1, 2 = FixedBeta<0|1|2>, anything else VariableBeta,
  * Beta.hpp); max_path and lights are not used by BPT.  SURVEY.md 8(f) rank 4 — first device version.
  *
- * mi_bpt_render: `spp` frames of the whole image.  Per frame every pixel traces one light sub-path and one eye sub-path
+ * mi_bpt_render: `spp` frames of the view window (w == 0: the whole image; splats that land outside the window are dropped, as
+ * _commit_images only commits the window).  Per frame every pixel traces one light sub-path and one eye sub-path
  * (BPT.cpp:13-101); connections to the camera are splatted into the frame's light image (Technique.cpp:276-306) and the sum
  * light + eye of a pixel passes the finite filter as one sample (Technique.cpp:194-244).  rgbn_sum as in mi_pt_render.
  * mi_bpt_trace_paths: parity hook — per listed (pixel, sample) the eye-image radiance, the sum of its light-image splats and
  * the counts (closest-hit rays, shadow rays, splats). */
-int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed,
+int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint64_t seed,
                   uint64_t sample_offset, float* rgbn_sum, mi_pt_stats* stats);
 int mi_bpt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_xy,
                        const uint64_t* sample_index, uint64_t seed, float* out_radiance, float* out_splat_sum, uint32_t* out_counts3);

@@ -141,7 +141,7 @@ def lib():
     L.mi_pt_intersect.argtypes = [vp, u32, vp, vp, vp, vp, vp]
     L.mi_pt_occluded.argtypes = [vp, u32, vp, vp, vp]
     L.mi_pt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp]
-    L.mi_bpt_render.argtypes = [vp, u32, u32, u32, u32, u64, u64, vp, C.POINTER(PtStats)]
+    L.mi_bpt_render.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, C.POINTER(PtStats)]
     L.mi_bpt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp, vp]
     L.mi_pt_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]
     L.mi_pt_bvh_download.argtypes = [vp, vp, vp, vp]
@@ -462,11 +462,12 @@ class PathTracing:
         _check(lib().mi_bpt_trace_paths(self._h, camera_id, width, height, n, _ptr(pixel_xy), _ptr(sample_index), seed, _ptr(rad), _ptr(spl), _ptr(cnt)))
         return rad, spl, cnt
 
-    def bpt_render_rgbn(self, width, height, spp=1, seed=0, sample_offset=0, camera_id=0):
-        """BPT: `spp` frames of the whole image -> [H][W][4] (R, G, B sums, denom)."""
+    def bpt_render_rgbn(self, width, height, spp=1, seed=0, sample_offset=0, camera_id=0, window=None):
+        """BPT: `spp` frames of the view window (default: whole image) -> [H][W][4] (R, G, B sums, denom)."""
         out = np.zeros((height, width, 4), np.float32)
         st = PtStats()
-        _check(lib().mi_bpt_render(self._h, camera_id, width, height, spp, seed, sample_offset, _ptr(out), C.byref(st)))
+        win = Window(*window) if window else Window(0, 0, 0, 0)
+        _check(lib().mi_bpt_render(self._h, camera_id, width, height, win, spp, seed, sample_offset, _ptr(out), C.byref(st)))
         self.last_stats = st
         return out
 

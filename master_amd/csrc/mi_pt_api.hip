@@ -609,16 +609,19 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
 }
 }  // namespace
 
-int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint64_t sample_offset,
-                  float* rgbn_sum, mi_pt_stats* stats) {
+int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint64_t seed,
+                  uint64_t sample_offset, float* rgbn_sum, mi_pt_stats* stats) {
   if (!h || !rgbn_sum) return fail(MI_ERR_INVALID_ARGUMENT, "mi_bpt_render: null argument");
   if (spp == 0) return fail(MI_ERR_INVALID_ARGUMENT, "spp must be > 0");
+  if (win.w == 0 || win.h == 0) { win.x0 = 0; win.y0 = 0; win.w = width; win.h = height; }
+  if (uint64_t(win.x0) + win.w > width || uint64_t(win.y0) + win.h > height)
+    return fail(MI_ERR_INVALID_ARGUMENT, "window exceeds the image");  // Technique.cpp:318-319 runtime_assert
   HIP_TRY(hipSetDevice(h->device));
   mi::RenderParams p; mi::BptState w; uint32_t per_launch = 0;
-  const uint64_t tiles_x = (uint64_t(width) + 7) / 8, tiles_y = (uint64_t(height) + 7) / 8, total = tiles_x * tiles_y * 64;
+  const uint64_t tiles_x = (uint64_t(win.w) + 7) / 8, tiles_y = (uint64_t(win.h) + 7) / 8, total = tiles_x * tiles_y * 64;
   int rc = bpt_prepare(h, camera_id, width, height, total, p, w, &per_launch);
   if (rc) return rc;
-  p.win_x0 = 0; p.win_y0 = 0; p.win_w = width; p.win_h = height; p.tiles_x = uint32_t(tiles_x); p.tiles_y = uint32_t(tiles_y);
+  p.win_x0 = win.x0; p.win_y0 = win.y0; p.win_w = win.w; p.win_h = win.h; p.tiles_x = uint32_t(tiles_x); p.tiles_y = uint32_t(tiles_y);
   p.spp = spp; p.seed = seed; p.sample_offset = sample_offset; p.n_chunks = 1;
   const size_t np = size_t(width) * height;
   rc = ensure(reinterpret_cast<void**>(&h->partial), &h->partial_bytes, np * 32); if (rc) return rc;
@@ -648,7 +651,7 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
     HIP_TRY(mi::bpt_launch_commit(p, w, stream));
   }
   HIP_TRY(hipEventRecord(h->ev1, stream));
-  HIP_TRY(mi::launch_finalize(h->partial, h->d_rgbn, width, height, 0, 0, width, height, 1, stream));
+  HIP_TRY(mi::launch_finalize(h->partial, h->d_rgbn, width, height, win.x0, win.y0, win.w, win.h, 1, stream));
   HIP_TRY(hipEventRecord(h->ev2, stream));
   unsigned long long c[24];
   HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));

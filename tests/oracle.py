@@ -40,7 +40,7 @@ def lib():
         L.orc_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp]
         L.orc_render.argtypes = [vp, u32, u32, u32, ma.Window, u32, u64, u64, vp, C.POINTER(ma.PtStats), C.c_int]
         L.orc_bpt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp, vp]
-        L.orc_bpt_render.argtypes = [vp, u32, u32, u32, u32, u64, u64, vp, C.POINTER(ma.PtStats), C.c_int]
+        L.orc_bpt_render.argtypes = [vp, u32, u32, u32, ma.Window, u32, u64, u64, vp, C.POINTER(ma.PtStats), C.c_int]
         L.orc_camera_setup.argtypes = [C.POINTER(ma.Camera), f32, C.POINTER(ma.CameraFrame)]
         L.orc_ray_direction.argtypes = [f32, f32, f32, f32, f32, C.POINTER(f32)]
         L.orc_pixel_position.argtypes = [C.POINTER(f32), f32, f32, f32, C.POINTER(f32)]
@@ -128,10 +128,11 @@ class Oracle:
         lib().orc_bpt_trace_paths(self._h, camera_id, width, height, n, _ptr(pixel_xy), _ptr(sample_index), C.c_uint64(seed), _ptr(rad), _ptr(spl), _ptr(cnt))
         return rad, spl, cnt
 
-    def bpt_render_rgbn(self, width, height, spp=1, seed=0, sample_offset=0, camera_id=0, threads=None):
+    def bpt_render_rgbn(self, width, height, spp=1, seed=0, sample_offset=0, camera_id=0, threads=None, window=None):
         out = np.zeros((height, width, 4), np.float32)
         st = ma.PtStats()
-        rc = lib().orc_bpt_render(self._h, camera_id, width, height, spp, C.c_uint64(seed), C.c_uint64(sample_offset), _ptr(out), C.byref(st),
+        win = ma.Window(*window) if window else ma.Window(0, 0, 0, 0)
+        rc = lib().orc_bpt_render(self._h, camera_id, width, height, win, spp, C.c_uint64(seed), C.c_uint64(sample_offset), _ptr(out), C.byref(st),
                                   threads or (os.cpu_count() or 1))
         assert rc == 0, rc
         self.last_stats = st

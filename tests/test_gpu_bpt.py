@@ -54,17 +54,23 @@ def test_bpt_beta_variants(cornell, beta):
         assert np.isclose(gr, orr, rtol=5e-5, atol=1e-7).all() and np.isclose(gs, os_, rtol=5e-5, atol=1e-7).all()
 
 
-@pytest.mark.parametrize("name,w,h", [("CornellBoxDiffuse", 64, 48), ("TestCase10", 37, 23), ("CornellBoxSpecular", 40, 40)])
-def test_bpt_render_equals_oracle(name, w, h):
-    """Frames: eye image + light image, one finite filter per pixel and frame (Technique.cpp:194-244); ragged sizes."""
+@pytest.mark.parametrize("name,w,h,window", [("CornellBoxDiffuse", 64, 48, None), ("TestCase10", 37, 23, None), ("CornellBoxSpecular", 40, 40, None),
+                                             ("CornellBoxDiffuse", 64, 48, (5, 7, 21, 30)), ("TestCase0", 130, 9, (120, 0, 10, 9))])
+def test_bpt_render_equals_oracle(name, w, h, window):
+    """Frames: eye image + light image, one finite filter per pixel and frame (Technique.cpp:194-244); ragged sizes and view
+    windows (only the window's pixels trace paths and are committed; their splats may land anywhere)."""
     s = load_scene(name)
     pt, orc = ma.PathTracing(s, beta=2.0), oracle.Oracle(s, beta=2.0)
-    img = pt.bpt_render_rgbn(w, h, spp=12, seed=5, sample_offset=2); ref = orc.bpt_render_rgbn(w, h, spp=12, seed=5, sample_offset=2, threads=8)
+    img = pt.bpt_render_rgbn(w, h, spp=12, seed=5, sample_offset=2, window=window); ref = orc.bpt_render_rgbn(w, h, spp=12, seed=5, sample_offset=2, threads=8, window=window)
+    if window:
+        x0, y0, ww, hh = window
+        mask = np.ones((h, w), bool); mask[y0:y0 + hh, x0:x0 + ww] = False
+        assert not img[mask].any()
     st, so = pt.last_stats, orc.last_stats
     assert (st.num_paths, st.num_basic_rays, st.num_shadow_rays, st.numeric_errors) == (so.num_paths, so.num_basic_rays, so.num_shadow_rays, so.numeric_errors)
     assert np.array_equal(img[..., 3], ref[..., 3])
     np.testing.assert_allclose(img, ref, rtol=2e-6, atol=0)  # FP64 splat order is free; everything else is exact
-    again = pt.bpt_render_rgbn(w, h, spp=12, seed=5, sample_offset=2)
+    again = pt.bpt_render_rgbn(w, h, spp=12, seed=5, sample_offset=2, window=window)
     np.testing.assert_allclose(img, again, rtol=2e-6, atol=0)
 
 

@@ -104,7 +104,10 @@ MI_DEV bool box_test(f3 lo, f3 hi, const RayBox& rb, float tmax, float& tnear) {
 // Per-lane traversal stack: the first `cap` levels live in LDS (stack[level * kBlock + tid]: consecutive
 // lanes hit consecutive banks); deeper levels — rare, traversal keeps few far children pending — go to a
 // private (scratch) array, so LDS per workgroup stays at `cap` KB however deep the LBVH is.
-constexpr uint32_t kStackSpill = 128;
+#ifndef MI_STACK_SPILL
+#define MI_STACK_SPILL 128
+#endif
+constexpr uint32_t kStackSpill = MI_STACK_SPILL;
 constexpr int kEmptyLink = 0x7FFFFFFF;  // unused child slot of a wide node
 // The LDS part is addressed through an address-space-3 pointer: with a generic pointer the compiler cannot prove the
 // target is LDS next to the private spill array and falls back to FLAT loads/stores with 64-bit address arithmetic

@@ -267,6 +267,9 @@ typedef struct mi_bvh_info {
  * light + eye of a pixel passes the finite filter as one sample (Technique.cpp:194-244).  rgbn_sum as in mi_pt_render.
  * mi_bpt_trace_paths: parity hook — per listed (pixel, sample) the eye-image radiance, the sum of its light-image splats and
  * the counts (closest-hit rays, shadow rays, splats). */
+/* Technique::set_sky_gradient (Technique.cpp:90-93; --sky-horizon / --sky-zenith / --blue-sky, Options.cpp:74-76): the colour a
+ * camera ray that leaves the scene returns in BPT (BPT.cpp:49-51); zero by default.  PT ignores the sky (PT.cpp:28,49-51). */
+int mi_bpt_set_sky(mi_pt_handle* h, const float horizon[3], const float zenith[3]);
 int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint64_t seed,
                   uint64_t sample_offset, float* rgbn_sum, mi_pt_stats* stats);
 int mi_bpt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_xy,

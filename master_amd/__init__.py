@@ -111,7 +111,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version",
     "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
-    "mi_bpt_render", "mi_bpt_trace_paths",
+    "mi_bpt_render", "mi_bpt_trace_paths", "mi_bpt_set_sky",
     "mi_pt_bvh_download", "mi_pt_blob_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
     "mi_scene_load", "mi_scene_save", "mi_scene_from_desc", "mi_scene_get_desc", "mi_scene_material_name", "mi_scene_mesh_name",
     "mi_scene_free", "mi_exr_save_rgbn", "mi_exr_load_rgbn", "mi_free", "mi_rms_abs_errors",
@@ -141,6 +141,7 @@ def lib():
     L.mi_pt_intersect.argtypes = [vp, u32, vp, vp, vp, vp, vp]
     L.mi_pt_occluded.argtypes = [vp, u32, vp, vp, vp]
     L.mi_pt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp]
+    L.mi_bpt_set_sky.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
     L.mi_bpt_render.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, C.POINTER(PtStats)]
     L.mi_bpt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp, vp]
     L.mi_pt_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]
@@ -452,6 +453,10 @@ class PathTracing:
         cnt = np.zeros((n, 2), np.uint32)
         _check(lib().mi_pt_trace_paths(self._h, camera_id, width, height, n, _ptr(pixel_xy), _ptr(sample_index), seed, _ptr(rad), _ptr(cnt)))
         return rad, cnt
+
+    def bpt_set_sky(self, horizon, zenith):
+        """Technique::set_sky_gradient: colour of camera rays that leave the scene (BPT only)."""
+        _check(lib().mi_bpt_set_sky(self._h, (C.c_float * 3)(*horizon), (C.c_float * 3)(*zenith)))
 
     def bpt_trace_paths(self, width, height, pixel_xy, sample_index, seed=0, camera_id=0):
         """BPT (BPT.cpp) per path: eye-image radiance, sum of light-image splats, (closest rays, shadow rays, splats)."""

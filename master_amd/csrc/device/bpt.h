@@ -25,6 +25,7 @@ struct BptState {
   double* light;           // [frames][H][W][3] light images (Technique::_light_image)
   float sphere[4];         // scene bounding sphere (loader.cpp:408-432) for the emitters' bounded cosine sampling
   float w2v[9];            // world_to_view_mat3 (Technique.cpp:40)
+  float sky_horizon[3], sky_zenith[3];  // Technique::set_sky_gradient: what a camera ray that leaves the scene returns (BPT.cpp:49-51)
   float* list_splat_sum; uint32_t* list_counts3;  // list mode outputs (mi_bpt_trace_paths)
 };
 

@@ -25,6 +25,7 @@ struct Ctx {
   const float4* sb; const SceneView* sv; TravStack* stack;
   float beta, roulette, rinv;
   f3 sphere_c; float sphere_r;
+  f3 sky_horizon, sky_zenith;
   uint32_t n_basic, n_shadow;
 };
 
@@ -348,7 +349,8 @@ MI_DEV f3 bpt_trace_eye(Ctx& c, Rng& g, const Cam& cam, const Surf& camera_surfa
     const BSample b = bpt_bsdf_sample(c, g, prev.surface, prev.omega);
     for (;;) {
       surface = scene_intersect<QN>(c, surface, b.omega, 0xFFFFFFFFu);
-      if (surface.material_id == 0xFFFFFFFFu) return at_camera ? F3(0, 0, 0) : radiance;  // sky_gradient is zero (Technique.hpp:46-47)
+      if (surface.material_id == 0xFFFFFFFFu)  // BPT.cpp:49-51: a camera ray that leaves the scene returns the sky gradient (Technique.cpp:86-88)
+        return at_camera ? (c.sky_horizon * (1 - b.omega.z) + c.sky_zenith * b.omega.z) * c.rinv : radiance;
       cur.surface = surface; cur.omega = -b.omega;
       const Edge e = make_edge(prev.surface, cur.surface, cur.omega);
       cur.throughput = (prev.throughput * b.q.throughput) * e.bCos;
@@ -449,6 +451,7 @@ MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, TravStack
   c.sb = sb; c.sv = sv; c.stack = stack;
   c.beta = p.beta; c.roulette = p.roulette; c.rinv = 1.0f / p.roulette;
   c.sphere_c = F3(w.sphere[0], w.sphere[1], w.sphere[2]); c.sphere_r = w.sphere[3];
+  c.sky_horizon = F3(w.sky_horizon[0], w.sky_horizon[1], w.sky_horizon[2]); c.sky_zenith = F3(w.sky_zenith[0], w.sky_zenith[1], w.sky_zenith[2]);
   c.n_basic = 0; c.n_shadow = 0;
 }
 
@@ -545,7 +548,10 @@ __global__ __launch_bounds__(kBlock, 4) void bpt_trace(const RenderParams p, con
           for (;;) {
             surface = scene_intersect<QN>(c, surface, b.omega, 0xFFFFFFFFu);
             if (surface.material_id == 0xFFFFFFFFu) {
-              if (at_camera) n_em = 0;  // BPT.cpp:45-47: a miss from the camera vertex returns the sky gradient (zero), not the radiance gathered through emitters
+              if (at_camera) {  // BPT.cpp:49-51: a miss from the camera vertex returns the sky gradient instead of what was gathered through emitters
+                const f3 sky = (c.sky_horizon * (1 - b.omega.z) + c.sky_zenith * b.omega.z) * c.rinv;
+                em[0] = make_float4(sky.x, sky.y, sky.z, __uint_as_float(0u)); n_em = 1;
+              }
               ended = true; break;
             }
             cur.surface = surface; cur.omega = -b.omega;
@@ -775,6 +781,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_WAVES) void bpt_frame(const RenderPa
     c.sb = p.sv.blob; c.sv = &p.sv; c.stack = &stack;
     c.beta = p.beta; c.roulette = p.roulette; c.rinv = 1.0f / p.roulette;
     c.sphere_c = F3(w.sphere[0], w.sphere[1], w.sphere[2]); c.sphere_r = w.sphere[3];
+    c.sky_horizon = F3(w.sky_horizon[0], w.sky_horizon[1], w.sky_horizon[2]); c.sky_zenith = F3(w.sky_zenith[0], w.sky_zenith[1], w.sky_zenith[2]);
     c.n_basic = 0; c.n_shadow = 0;
     const m33 v2w = {F3(p.v2w[0], p.v2w[1], p.v2w[2]), F3(p.v2w[3], p.v2w[4], p.v2w[5]), F3(p.v2w[6], p.v2w[7], p.v2w[8])};
     Cam cam;

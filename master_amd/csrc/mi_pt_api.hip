@@ -55,6 +55,7 @@ struct mi_pt_handle {
   float* bpt_eye = nullptr; size_t bpt_eye_bytes = 0;
   double* bpt_light = nullptr; size_t bpt_light_bytes = 0;
   float sphere[4] = {0, 0, 0, 0};
+  float sky_horizon[3] = {0, 0, 0}, sky_zenith[3] = {0, 0, 0};
 };
 
 namespace {
@@ -579,6 +580,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   if (rc) return rc;
   std::memcpy(w.w2v, fr.world_to_view, sizeof w.w2v);
   std::memcpy(w.sphere, h->sphere, sizeof w.sphere);
+  std::memcpy(w.sky_horizon, h->sky_horizon, sizeof w.sky_horizon); std::memcpy(w.sky_zenith, h->sky_zenith, sizeof w.sky_zenith);
   uint64_t lanes = total_lanes < (1ull << 20) ? total_lanes : (1ull << 20);  // up to 1 M paths per launch
   lanes = (lanes + 255) / 256 * 256;
   const bool staged = bpt_staged();
@@ -608,6 +610,12 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   return MI_OK;
 }
 }  // namespace
+
+int mi_bpt_set_sky(mi_pt_handle* h, const float horizon[3], const float zenith[3]) {
+  if (!h || !horizon || !zenith) return fail(MI_ERR_INVALID_ARGUMENT, "mi_bpt_set_sky: null argument");
+  std::memcpy(h->sky_horizon, horizon, 12); std::memcpy(h->sky_zenith, zenith, 12);
+  return MI_OK;
+}
 
 int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint64_t seed,
                   uint64_t sample_offset, float* rgbn_sum, mi_pt_stats* stats) {

@@ -222,6 +222,7 @@ typedef struct orc_scene {
   /* PT params */
   mi_pt_params p;
   int use_bvh;
+  float sky_horizon[3], sky_zenith[3]; /* Technique::_sky_horizon / _sky_zenith (Technique.hpp:46-47), used by BPT only */
 } orc_scene;
 
 typedef struct {

@@ -39,6 +39,8 @@ def lib():
         L.orc_occluded.argtypes = [vp, u32, vp, vp, vp]
         L.orc_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp]
         L.orc_render.argtypes = [vp, u32, u32, u32, ma.Window, u32, u64, u64, vp, C.POINTER(ma.PtStats), C.c_int]
+        L.orc_bpt_set_sky.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
+        L.orc_bpt_set_sky.restype = None
         L.orc_bpt_trace_paths.argtypes = [vp, u32, u32, u32, u32, vp, vp, u64, vp, vp, vp]
         L.orc_bpt_render.argtypes = [vp, u32, u32, u32, ma.Window, u32, u64, u64, vp, C.POINTER(ma.PtStats), C.c_int]
         L.orc_camera_setup.argtypes = [C.POINTER(ma.Camera), f32, C.POINTER(ma.CameraFrame)]
@@ -118,6 +120,9 @@ class Oracle:
         cnt = np.zeros((n, 2), np.uint32)
         lib().orc_trace_paths(self._h, camera_id, width, height, n, _ptr(pixel_xy), _ptr(sample_index), seed, _ptr(rad), _ptr(cnt))
         return rad, cnt
+
+    def bpt_set_sky(self, horizon, zenith):
+        lib().orc_bpt_set_sky(self._h, _f3(horizon), _f3(zenith))
 
     def bpt_trace_paths(self, width, height, pixel_xy, sample_index, seed=0, camera_id=0):
         """BPT (BPT.cpp): per path the eye-image radiance, the float sum of its light-image splats, and (closest, shadow, splats) counts."""

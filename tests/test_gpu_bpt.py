@@ -121,6 +121,19 @@ def test_bpt_one_kernel_form_equals_staged_form(monkeypatch, name):
     np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)
 
 
+def test_bpt_sky_gradient():
+    """--sky-horizon / --sky-zenith (Options.cpp:74-76): camera rays that leave the scene return the gradient times 1/roulette."""
+    s = load_scene("TestCase0")  # a lit plane under an open sky
+    pt, orc = ma.PathTracing(s, beta=2.0), oracle.Oracle(s, beta=2.0)
+    pt.bpt_set_sky((0.5, 0.25, 0.125), (0.0, 0.0, 2.0)); orc.bpt_set_sky((0.5, 0.25, 0.125), (0.0, 0.0, 2.0))
+    xy, si = _paths(64, 48, 6000, 3)
+    gr, gs, gc = pt.bpt_trace_paths(64, 48, xy, si, seed=1); orr, os_, oc = orc.bpt_trace_paths(64, 48, xy, si, seed=1)
+    assert np.array_equal(gc, oc) and _bits_equal(gr, orr).all() and _bits_equal(gs, os_).all()
+    assert (gr[:, 2] != gr[:, 0]).any()  # the sky is visible
+    img = pt.bpt_render_rgbn(48, 36, spp=8, seed=2); ref = orc.bpt_render_rgbn(48, 36, spp=8, seed=2, threads=8)
+    np.testing.assert_allclose(img, ref, rtol=2e-6, atol=0)
+
+
 def test_bpt_error_behaviour(cornell):
     pt = ma.PathTracing(cornell)
     with pytest.raises(ma.MiError):

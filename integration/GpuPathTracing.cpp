@@ -84,6 +84,7 @@ void GpuPathTracing::render(subimage_view_t& view, RandomEngine&, size_t cameraI
   _rgbn.resize(view.width() * view.height() * 4);
   mi_window win = {uint32_t(view.xBegin()), uint32_t(view.yBegin()), uint32_t(view.xWindow()), uint32_t(view.yWindow())};
   mi_pt_stats st = {};
+  if (_bidirectional) check(mi_bpt_set_sky(_handle, &_sky_horizon.x, &_sky_zenith.x));  // Technique::set_sky_gradient (Technique.cpp:90-93)
   if (_bidirectional)  // light-image splats land anywhere; light + eye are committed per frame inside, for the window only
     check(mi_bpt_render(_handle, uint32_t(cameraId), uint32_t(view.width()), uint32_t(view.height()), win,
                         /*spp=*/1, _seed, /*sample_offset=*/_statistics.num_samples, _rgbn.data(), &st));

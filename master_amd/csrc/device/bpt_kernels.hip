@@ -849,8 +849,8 @@ __global__ __launch_bounds__(256) void bpt_commit(const RenderParams p, const Bp
 hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list, hipStream_t stream) {
   const size_t lds = size_t(p.stack_entries) * kBlock * 4;
   const dim3 grid((w.lanes + kBlock - 1) / kBlock), block(kBlock);
-  if (list) { if (p.wide_nodes) hipLaunchKernelGGL((bpt_frame<true, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_frame<true, 1>), grid, block, lds, stream, p, w); }
-  else { if (p.wide_nodes) hipLaunchKernelGGL((bpt_frame<false, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_frame<false, 1>), grid, block, lds, stream, p, w); }
+  if (list) { if (p.wide_nodes == 1u) hipLaunchKernelGGL((bpt_frame<true, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_frame<true, 1>), grid, block, lds, stream, p, w); }
+  else { if (p.wide_nodes == 1u) hipLaunchKernelGGL((bpt_frame<false, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_frame<false, 1>), grid, block, lds, stream, p, w); }
   return hipGetLastError();
 }
 // staged form: trace + scan (returns the number of connection items of the launch's paths), then items + gather
@@ -861,7 +861,7 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
   if (e != hipSuccess) return e;
   void (*fn)(const RenderParams, const BptState) = nullptr;
   if (lds_scene) fn = list ? bpt_trace<true, 0> : bpt_trace<false, 0>;
-  else if (p.wide_nodes) fn = list ? bpt_trace<true, 2> : bpt_trace<false, 2>;
+  else if (p.wide_nodes == 1u) fn = list ? bpt_trace<true, 2> : bpt_trace<false, 2>;
   else fn = list ? bpt_trace<true, 1> : bpt_trace<false, 1>;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;
@@ -884,7 +884,7 @@ hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list
     const dim3 grid((total_items + kBlock - 1) / kBlock), block(kBlock);
     void (*fn)(const RenderParams, const BptState, uint32_t, uint32_t) = nullptr;
     if (lds_scene) fn = list ? bpt_items<true, 0> : bpt_items<false, 0>;
-    else if (p.wide_nodes) fn = list ? bpt_items<true, 2> : bpt_items<false, 2>;
+    else if (p.wide_nodes == 1u) fn = list ? bpt_items<true, 2> : bpt_items<false, 2>;
     else fn = list ? bpt_items<true, 1> : bpt_items<false, 1>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;

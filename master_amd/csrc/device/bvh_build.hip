@@ -422,15 +422,15 @@ __global__ void k_emit(uint32_t n, const uint32_t* __restrict__ sorted_tri, cons
   for (int k = 0; k < 8; ++k) tri_shade[8 * size_t(i) + k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
 }
 
-// 16-bit grid coordinates of the child boxes, rounded outward by one extra cell so that float rounding in the
-// ray's grid transform can never cut into the true box.
+// 16-bit grid coordinates of the child boxes, rounded outward (plus 1/16 cell: the float grid transform of the box corners and of
+// the ray is good to ~0.01 cell) so that rounding can never cut into the true box.  The slab test adds its own per-ray slack.
 __device__ __forceinline__ uint32_t q_lo(float v, float lo, float inv_step) {
-  float q = floorf((v - lo) * inv_step) - 1.0f;
+  float q = floorf((v - lo) * inv_step - 0.0625f);  // the float grid transform is good to ~0.01 cell at 65 535: 1/16 cell of slack
   q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q);
   return uint32_t(q);
 }
 __device__ __forceinline__ uint32_t q_hi(float v, float lo, float inv_step) {
-  float q = ceilf((v - lo) * inv_step) + 1.0f;
+  float q = ceilf((v - lo) * inv_step + 0.0625f);
   q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q);
   return uint32_t(q);
 }

@@ -52,7 +52,8 @@ struct RenderParams {
   uint32_t win_x0, win_y0, win_w, win_h;
   uint32_t tiles_x, tiles_y;
   uint32_t stack_entries;  // per-lane traversal stack capacity (LDS), >= BVH depth
-  uint32_t wide_nodes;     // HBM-resident kernels: 1 = walk the 64-byte wide nodes with the 7-wave register budget (large scenes)
+  uint32_t wide_nodes;     // HBM-resident kernels: 0 = 32-byte quantised binary nodes, 1 = 64-byte quantised wide nodes with the 7-wave
+                           // register budget (large scenes), 2 = full-precision 64-byte binary nodes (grid too coarse for the scene)
   // sample range
   uint32_t spp, n_chunks, chunk_spp;
   uint64_t seed, sample_offset;

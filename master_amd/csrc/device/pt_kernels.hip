@@ -440,7 +440,11 @@ size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream) {
   const size_t lds = pt_lds_bytes(p, lds_scene);
   void (*fn)(const RenderParams) = nullptr;
-  const bool large = p.wide_nodes != 0u;
+  const bool large = p.wide_nodes == 1u;
+  if (!lds_scene && p.wide_nodes == 2u) {  // full-precision 64-byte nodes from HBM: scenes whose triangles are small against the 16-bit grid
+    if (count) fn = pt_megakernel<false, false, true, MI_WAVES_HBM, 0>;
+    else fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM, 0> : pt_megakernel<false, false, false, MI_WAVES_HBM, 0>;
+  } else
   if (count) fn = lds_scene ? pt_megakernel<true, false, true, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, false, true, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, false, true, MI_WAVES_HBM, 1>);
   else if (lds_scene) fn = list ? pt_megakernel<true, true, false, MI_WAVES_LDS, 0> : pt_megakernel<true, false, false, MI_WAVES_LDS, 0>;
   else if (large) fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, false, false, MI_WAVES_HBM_LARGE, 2>;

@@ -3,6 +3,7 @@
 // CPU fallback — without a HIP device every compute entry point fails with MI_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +32,7 @@ struct mi_pt_handle {
   float4* blob = nullptr;
   uint4* qnodes = nullptr;
   uint4* qnodes4 = nullptr;
+  bool float_nodes = false;        // HBM-resident kernels read the full-precision nodes: the 16-bit grid is too coarse for this scene
   bool wide_nodes = false;         // HBM-resident kernels walk the wide nodes (scenes of >= 100 000 triangles; MI_PT_WIDE_NODES=0/1 overrides)
   uint32_t stack_entries_hbm = 0;  // LDS rows of the traversal stack for kernels that read the scene from HBM (wide walk)
   mi::SceneView sv{};
@@ -127,7 +129,7 @@ int fill_camera(const mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint3
 
 void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   p.sv = h->sv;
-  p.wide_nodes = h->wide_nodes ? 1u : 0u;
+  p.wide_nodes = h->float_nodes ? 2u : (h->wide_nodes ? 1u : 0u);
   p.stack_entries = (use_lds_scene(h) && h->kernel_choice != MI_PT_KERNEL_WAVEFRONT) ? h->info.stack_entries : h->stack_entries_hbm;
   const uint64_t mp = h->params.max_path;
   p.max_path = mp >= 0x03FFFFFFull ? 0xFFFFFFFFu : uint32_t(mp);  // the kernel's path_size field has 26 bits: >= 2^26 - 1 edges = unlimited
@@ -284,6 +286,26 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     h->stack_entries_hbm = se4;
     h->wide_nodes = nt >= 100000u;
     if (const char* e = std::getenv("MI_PT_WIDE_NODES")) h->wide_nodes = std::atoi(e) != 0;
+    // Is the 16-bit grid fine enough for this scene?  Median triangle box, longest side in grid cells: far-away light quads
+    // stretch the scene box of some of the reference's models (MetalRings: 400 units around 0.1-unit triangles, 16 cells per
+    // triangle), and boxes rounded outward to whole cells then overlap their neighbours (16 instead of 9 triangle tests per ray).
+    // Below 24 cells the kernels read the full-precision 64-byte nodes instead (+9 % on MetalRings; -10..-25 % on well-scaled scenes).
+    {
+      std::vector<float> cells(nt);
+      for (uint32_t t = 0; t < nt; ++t) {
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int k = 0; k < 3; ++k) {
+          const float* q = &s.positions[3 * size_t(s.indices[3 * size_t(t) + k])];
+          for (int a = 0; a < 3; ++a) { if (q[a] < lo[a]) lo[a] = q[a]; if (q[a] > hi[a]) hi[a] = q[a]; }
+        }
+        float m = 0.0f, coarsest = h->sv.grid_inv_step[0];  // longest side of the triangle's box, in cells of the coarsest axis of the grid
+        for (int a = 0; a < 3; ++a) { if (hi[a] - lo[a] > m) m = hi[a] - lo[a]; if (h->sv.grid_inv_step[a] < coarsest) coarsest = h->sv.grid_inv_step[a]; }
+        cells[t] = m * coarsest;
+      }
+      std::nth_element(cells.begin(), cells.begin() + nt / 2, cells.end());
+      h->float_nodes = cells[nt / 2] < 24.0f && !h->wide_nodes;
+      if (const char* e = std::getenv("MI_PT_FLOAT_NODES")) h->float_nodes = std::atoi(e) != 0;
+    }
   }
   // scene bounding sphere for the emitters' bounded cosine sampling (BPT): the loader's value, or compute_bounding_sphere
   // (loader.cpp:408-432) over the surface meshes when the description carries none

@@ -580,13 +580,35 @@ bool bpt_staged() {  // MI_BPT_STAGED=0 selects the one-kernel form (kept for A/
 // one launch of `w.lanes` paths: the one-kernel form, or trace -> (item count) -> items -> gather
 int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool list, hipStream_t stream) {
   if (!bpt_staged()) { HIP_TRY(mi::bpt_launch_frame(p, w, list, stream)); return MI_OK; }
-  uint32_t total = 0;
   const bool lds = use_lds_scene(h);  // small scenes: padded copy of the blob in LDS, binary walk
-  HIP_TRY(mi::bpt_stage_trace(p, w, list, lds, stream, &total));
-  int rc = ensure(reinterpret_cast<void**>(&h->bpt_values), &h->bpt_values_bytes, size_t(total ? total : 1) * 16);
-  if (rc) return rc;
-  w.values = h->bpt_values;
-  HIP_TRY(mi::bpt_stage_connect(p, w, list, lds, total, stream));
+  auto run = [&](mi::BptState& ws, bool* overflow) -> int {
+    uint32_t total = 0;
+    HIP_TRY(mi::bpt_stage_trace(p, ws, list, lds, stream, &total));
+    unsigned long long over = 0;
+    HIP_TRY(hipMemcpy(&over, h->d_counters + 15, sizeof over, hipMemcpyDeviceToHost));
+    if (over) { *overflow = true; HIP_TRY(hipMemsetAsync(h->d_counters + 15, 0, sizeof over, stream)); return MI_OK; }
+    int rc = ensure(reinterpret_cast<void**>(&h->bpt_values), &h->bpt_values_bytes, size_t(total ? total : 1) * 16);
+    if (rc) return rc;
+    ws.values = h->bpt_values;
+    HIP_TRY(mi::bpt_stage_connect(p, ws, list, lds, total, stream));
+    return MI_OK;
+  };
+  bool overflow = false;
+  int rc = run(w, &overflow);
+  if (rc || !overflow) return rc;
+  // A sub-path outgrew the slab share of this launch (long paths: roulette close to 1).  The same memory holds fewer paths at
+  // the reference's own capacity of 1024 vertices (BPT.hpp:30): redo the launch in slices.
+  const uint64_t slice = uint64_t(w.lanes) * w.max_vertices / 1024u;
+  if (slice == 0 || w.max_vertices >= 1024u) return fail(MI_ERR_UNSUPPORTED, "BPT: a sub-path exceeds 1024 vertices (the reference's fixed_vector capacity)");
+  const uint32_t first = w.first, lanes = w.lanes;
+  for (uint32_t done = 0; done < lanes; done += uint32_t(slice)) {
+    mi::BptState ws = w;
+    ws.first = first + done; ws.lanes = lanes - done < slice ? lanes - done : uint32_t(slice); ws.max_vertices = 1024u;
+    bool again = false;
+    rc = run(ws, &again);
+    if (rc) return rc;
+    if (again) return fail(MI_ERR_UNSUPPORTED, "BPT: a sub-path exceeds 1024 vertices (the reference's fixed_vector capacity)");
+  }
   return MI_OK;
 }
 // buffers and per-launch constants shared by the two BPT entry points
@@ -606,9 +628,11 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   uint64_t lanes = total_lanes < (1ull << 20) ? total_lanes : (1ull << 20);  // up to 1 M paths per launch
   lanes = (lanes + 255) / 256 * 256;
   const bool staged = bpt_staged();
-  uint64_t cap = (staged ? (16ull << 30) : (24ull << 30)) / (lanes * 112ull);  // vertex slabs: 3 x 16 GB (staged) or 24 GB of the 288 GB
+  uint64_t budget = staged ? (16ull << 30) : (24ull << 30);  // vertex slabs: 3 x 16 GB (staged) or 24 GB of the 288 GB
+  if (const char* e = std::getenv("MI_BPT_SLAB_MB")) { const long long v = std::atoll(e); if (v > 0) budget = uint64_t(v) << 20; }
+  uint64_t cap = budget / (lanes * 112ull);
   if (cap > 1024) cap = 1024;
-  if (cap < 64) cap = 64;
+  if (cap < 16) cap = 16;
   w.max_vertices = uint32_t(cap);
   if (staged) {
     const size_t slab = size_t(lanes) * cap * 112;

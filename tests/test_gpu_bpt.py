@@ -121,6 +121,18 @@ def test_bpt_one_kernel_form_equals_staged_form(monkeypatch, name):
     np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)
 
 
+def test_bpt_long_paths_fall_back_to_the_reference_capacity(monkeypatch):
+    """roulette 0.97 in a closed furnace: sub-paths of a hundred vertices.  With a tiny slab budget the first attempt overflows and
+    the launch is redone in slices at 1024 vertices per sub-path (BPT.hpp:30) — same bits as the oracle."""
+    s = load_scene("TestCaseFurnace")
+    monkeypatch.setenv("MI_BPT_SLAB_MB", "4")
+    pt, orc = ma.PathTracing(s, beta=2.0, roulette=0.97), oracle.Oracle(s, beta=2.0, roulette=0.97)
+    xy, si = _paths(32, 32, 1500, 2)
+    gr, gs, gc = pt.bpt_trace_paths(32, 32, xy, si, seed=4); orr, os_, oc = orc.bpt_trace_paths(32, 32, xy, si, seed=4)
+    assert gc[:, 0].max() > 100  # long paths indeed
+    assert np.array_equal(gc, oc) and _bits_equal(gr, orr).all() and _bits_equal(gs, os_).all()
+
+
 def test_bpt_sky_gradient():
     """--sky-horizon / --sky-zenith (Options.cpp:74-76): camera rays that leave the scene return the gradient times 1/roulette."""
     s = load_scene("TestCase0")  # a lit plane under an open sky

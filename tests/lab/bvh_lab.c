@@ -104,18 +104,31 @@ static int split_rec(const poly_t* q, int levels, prim_t* out, int32_t leaf) {
   int n = split_rec(&l, levels - 1, out, leaf);
   return n + split_rec(&r, levels - 1, out + n, leaf);
 }
-static int g_split_levels_max = 0;
+static int g_split_levels_max = 0, g_split_big = 0;
 ORC_API void lab_set_split(int max_levels) { g_split_levels_max = max_levels; }
+ORC_API void lab_set_split_big(int factor) { g_split_big = factor; } /* also split boxes whose longest side exceeds factor x the median */
+static int cmp_f(const void* a, const void* b) { float x = *(const float*)a, y = *(const float*)b; return x < y ? -1 : x > y ? 1 : 0; }
 
 ORC_API void lab_build_sah(orc_scene* s) {
   int n = (int)s->d.n_triangles;
   if (n < 2) return;
-  prim_t* p = (prim_t*)malloc(sizeof(prim_t) * (size_t)n * 16);
+  prim_t* p = (prim_t*)malloc(sizeof(prim_t) * (size_t)n * 64);
   int np = 0;
+  float median = 0.0f;
+  if (g_split_big > 0) {
+    float* ext = (float*)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) { float lo[3], hi[3]; tri_bounds(s, s->sorted_tri[i], lo, hi); ext[i] = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]); }
+    qsort(ext, (size_t)n, sizeof(float), cmp_f); median = ext[n / 2]; free(ext);
+  }
   for (int i = 0; i < n; ++i) {
     float lo[3], hi[3]; tri_bounds(s, s->sorted_tri[i], lo, hi);
     int levels = 0;
-    if (g_split_levels_max > 0) {
+    if (g_split_big > 0) {
+      float e = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+      float ratio = e / (median * (float)g_split_big);
+      while (levels < 6 && ratio > 1.0f) { ++levels; ratio *= 0.7071f; } /* each bisection of the longest axis shrinks it by ~sqrt(2) on average */
+    }
+    if (g_split_levels_max > 0 && levels == 0) {
       const tri_t* t = &s->tris_sorted[i];
       float at = sqrtf(vdot(t->ng, t->ng));                 /* 2 x triangle area */
       float ab = 2.0f * box_area(lo, hi);                   /* box surface area */

@@ -42,6 +42,7 @@ def main():
             o = oracle.Oracle(s)
             if variant.startswith("sah"):
                 L.lab_set_split(int(variant[3]) if len(variant) > 3 and variant[3].isdigit() else 0)
+                L.lab_set_split_big(int(variant.split("big")[1]) if "big" in variant else 0)
                 L.lab_build_sah(o._h)
             rot = L.lab_rotate(o._h, 8) if variant.endswith("+rot") else 0
             cnt = (C.c_uint64 * 4)()

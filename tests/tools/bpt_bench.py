@@ -2,7 +2,7 @@
 """BPT throughput on the GPU next to the CPU restatement (informational; bench.py stays on the PT north-star metric).
 Samples = closest-hit rays (eye + light sub-path segments), like num_basic_rays of the reference's statistics."""
 import json, os, sys, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import master_amd as ma

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU check of the BPT kernels against the BPT oracle: per-path eye radiance / splat sums / counts, image means."""
 import os, sys, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import master_amd as ma

@@ -2,7 +2,7 @@
 """the CPU restatement (oracle) on this host's cores.
 C1 = CornellBoxDiffuse 256x256, 64 spp, max path 4, median of 3;  C2-cpu = 512x512, 16 spp, max path 8."""
 import json, os, statistics, sys, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import master_amd as ma, oracle
 sys.path.insert(0, ROOT)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Large-scene check on a GPU box: parity of a sample of paths vs the oracle + throughput + traversal stats."""
 import os, sys, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np, master_amd as ma, oracle
 from master_amd import scenegen as procedural

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """First-contact diagnostics on a GPU box: prints parity numbers instead of asserting."""
 import os, sys, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import master_amd as ma

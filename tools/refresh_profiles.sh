@@ -14,7 +14,7 @@ if [ "${1:-core}" = core ]; then
   python tools/pmc_to_traffic.py profiles/r01/pmc_summary_c2.txt CornellBoxDiffuse_512x512x1024_mp8 > $O/traffic_c2.json
   cp profiles/traffic.json $O/traffic.json
   python bench.py --steps 5 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err
-  python tools/cpu_baseline_c1.py > $O/cpu_restatement_c1_c2.json 2> $O/cpu_restatement.err
+  python tests/tools/cpu_baseline_c1.py > $O/cpu_restatement_c1_c2.json 2> $O/cpu_restatement.err
   python tools/time_to_rmse.py > $O/time_to_rmse_c2.json 2> $O/time_to_rmse.err
 else
   run() { python bench.py --scene "$1" --width $2 --height $3 --spp $4 --max-path 0 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_full_$5.json 2> $O/bench_full_$5.err; }

@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
     ap.add_argument("--max-path", type=int, default=8, help="0 = unlimited (roulette-terminated), the reference default")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 megakernel with the scene in LDS, 2 megakernel with the scene in HBM, 3 wavefront pipeline")
+    ap.add_argument("--shard", choices=("samples", "tiles"), default="samples",
+                    help="multi-GPU decomposition: sample ranges (default) or interleaved 32x32 pixel tiles (BASELINE C5); work per GPU is the same")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses N ranks on one GPU")
@@ -131,9 +133,16 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     seed = 0x5EED
 
+    tiles = args.shard == "tiles" and world > 1
+    if tiles:
+        pt.set_tile_shard(rank, world)
+
     def step(i):
-        st = pt.render_device(fb.data_ptr(), W, H, spp=args.spp, seed=seed, sample_offset=madist.sample_offset(i, rank, world, args.spp),
-                              stream=stream, want_stats=True)
+        if tiles:  # this rank's 32x32 tiles, all world x spp samples of the step
+            off, n = madist.tile_sample_range(i, world, args.spp)
+        else:      # every pixel, this rank's spp samples of the step
+            off, n = madist.sample_offset(i, rank, world, args.spp), args.spp
+        st = pt.render_device(fb.data_ptr(), W, H, spp=n, seed=seed, sample_offset=off, stream=stream, want_stats=True)
         madist.merge_framebuffers(fb)  # RCCL all-reduce (sum) of (R, G, B, denom): merge_exr semantics
         return st
 
@@ -198,7 +207,7 @@ def main():
                            "unlimited" if args.max_path >= ma.PTRDIFF_MAX else args.max_path,
                            " (BASELINE configs[1])" if (args.scene, W, H, args.spp, args.max_path) == ("CornellBoxDiffuse", 512, 512, 1024, 8) else ""),
                        "kernel": {1: "pt_megakernel<LDS scene>", 2: "pt_megakernel<HBM scene>", 3: "wavefront pipeline (wf_extend / wf_shade / wf_shadow / wf_regen)"}[pt.get_kernel()],
-                       "parallelism": "samples sharded over %d GPU(s), RCCL all-reduce of [H][W][4] f32" % world,
+                       "parallelism": "%s sharded over %d GPU(s), RCCL all-reduce of [H][W][4] f32" % ("32x32 pixel tiles" if tiles else "samples", world),
                        "Mpaths_per_s": paths / elapsed / 1e6, "Mrays_per_s": (segs + shadow) / elapsed / 1e6,
                        "denom_equals_spp": denom_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -182,6 +182,15 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
                         mi_window win, uint32_t spp, uint64_t seed, uint64_t sample_offset,
                         float* rgbn_sum_device, void* stream, mi_pt_stats* stats);
 
+/* Pixel-tile sharding of mi_pt_render / mi_pt_render_device across `world` processes (one per GPU):
+ * the window is cut into the 32x32 tiles of Technique::_trace_paths (Technique.cpp:167, exec2d
+ * threadpool.cpp:190-233), numbered row-major from the window's origin, and this handle renders
+ * the tiles {t : t mod world == rank}; every other pixel is written as zeros (R, G, B and denom),
+ * so the sum of the ranks' framebuffers — merge_exr (Options.cpp:1356-1358), one RCCL reduce — is
+ * bit-identical to the unsharded render.  world <= 1 switches sharding off (the default).
+ * The other way to shard, by sample ranges, needs no call: see sample_offset above. */
+int mi_pt_set_tile_shard(mi_pt_handle* h, uint32_t rank, uint32_t world);
+
 /* Replaces: reading the message of std::logic_error / std::runtime_error thrown by the
  * reference (runtime_assert.cpp:7-11).  Thread-local, never NULL. */
 const char* mi_pt_last_error(void);

@@ -110,7 +110,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 # every symbol include/mi_pt.h declares; tests/test_abi.py checks the library exports them all
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version",
-    "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
+    "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_tile_shard", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
     "mi_bpt_render", "mi_bpt_trace_paths", "mi_bpt_set_sky",
     "mi_pt_bvh_download", "mi_pt_blob_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
     "mi_scene_load", "mi_scene_save", "mi_scene_from_desc", "mi_scene_get_desc", "mi_scene_material_name", "mi_scene_mesh_name",
@@ -136,6 +136,7 @@ def lib():
     L.mi_pt_render.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, C.POINTER(PtStats)]
     L.mi_pt_render_device.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, vp, C.POINTER(PtStats)]
     L.mi_pt_set_kernel.argtypes = [vp, C.c_int]
+    L.mi_pt_set_tile_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.mi_pt_get_kernel.argtypes = [vp]
     L.mi_pt_set_instrumented.argtypes = [vp, C.c_int]
     L.mi_pt_intersect.argtypes = [vp, u32, vp, vp, vp, vp, vp]
@@ -420,6 +421,10 @@ class PathTracing:
     # -- scene services (parity hooks) -------------------------------------------------------
     def set_kernel(self, kernel):
         _check(lib().mi_pt_set_kernel(self._h, kernel))
+
+    def set_tile_shard(self, rank, world):
+        """Render only the 32x32 tiles {t : t mod world == rank} of the window (Technique.cpp:167); world <= 1 = off."""
+        _check(lib().mi_pt_set_tile_shard(self._h, rank, world))
 
     def get_kernel(self):
         return lib().mi_pt_get_kernel(self._h)

@@ -51,6 +51,7 @@ struct RenderParams {
   uint32_t width, height;
   uint32_t win_x0, win_y0, win_w, win_h;
   uint32_t tiles_x, tiles_y;
+  uint32_t shard_rank, shard_world, shard_mtx;  // pixel-tile sharding (mi_pt_set_tile_shard): world > 1 = on, mtx = 32x32 tiles per window row
   uint32_t stack_entries;  // per-lane traversal stack capacity (LDS), >= BVH depth
   uint32_t wide_nodes;     // HBM-resident kernels: 0 = 32-byte quantised binary nodes, 1 = 64-byte quantised wide nodes with the 7-wave
                            // register budget (large scenes), 2 = full-precision 64-byte binary nodes (grid too coarse for the scene)
@@ -67,5 +68,20 @@ struct RenderParams {
   const uint32_t* list_xy; const uint64_t* list_sample; uint32_t list_n;
   float* list_radiance; uint32_t* list_counts;
 };
+
+// Origin of wave tile `tile` (8x8 pixels).  Unsharded: row-major over the window.  Sharded: the rank's k-th 32x32 tile
+// (Technique.cpp:167) is tile k * world + rank of the window, and holds 16 wave tiles.
+__device__ __forceinline__ void tile_origin(const RenderParams& p, uint32_t tile, uint32_t& x0, uint32_t& y0) {
+  if (p.shard_world > 1u) {
+    const uint32_t m = (tile >> 4) * p.shard_world + p.shard_rank, micro = tile & 15u;
+    const uint32_t my = m / p.shard_mtx, mx = m - my * p.shard_mtx;
+    x0 = p.win_x0 + mx * 32u + (micro & 3u) * 8u;
+    y0 = p.win_y0 + my * 32u + (micro >> 2) * 8u;
+  } else {
+    const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    x0 = p.win_x0 + tx * 8u;
+    y0 = p.win_y0 + ty * 8u;
+  }
+}
 
 }  // namespace mi

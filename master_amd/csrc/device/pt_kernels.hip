@@ -104,9 +104,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
     const uint32_t tile = logical_wave / p.n_chunks;
     chunk = logical_wave - tile * p.n_chunks;
     const bool valid = tile < n_tiles;
-    const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    tile_x0 = p.win_x0 + tx * 8u;
-    tile_y0 = p.win_y0 + ty * 8u;
+    tile_origin(p, valid ? tile : 0u, tile_x0, tile_y0);
     const uint32_t s0 = chunk * p.chunk_spp;
     const uint32_t s1 = s0 + p.chunk_spp < p.spp ? s0 + p.chunk_spp : p.spp;
     chunk_sample0 = p.sample_offset + s0;

@@ -75,8 +75,9 @@ MI_DEV void slot_next_path(const RenderParams& p, const WfState& w, uint32_t slo
     if (have) { px = p.list_xy[2 * item]; py = p.list_xy[2 * item + 1]; sample = p.list_sample[item]; }
   } else {
     const uint32_t tile = ps >> 6, pix = ps & 63u;
-    const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    px = p.win_x0 + tx * 8u + (pix & 7u); py = p.win_y0 + ty * 8u + (pix >> 3);
+    uint32_t tx0, ty0;
+    tile_origin(p, tile, tx0, ty0);
+    px = tx0 + (pix & 7u); py = ty0 + (pix >> 3);
     const uint64_t s = uint64_t(r) + uint64_t(k) * w.R;
     have = s < p.spp && px < p.win_x0 + p.win_w && py < p.win_y0 + p.win_h;
     sample = p.sample_offset + s;
@@ -311,8 +312,9 @@ __global__ __launch_bounds__(256) void wf_reduce(const RenderParams p, const WfS
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= w.per_sample) return;
   const uint32_t tile = i >> 6, pix = i & 63u;
-  const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-  const uint32_t px = p.win_x0 + tx * 8u + (pix & 7u), py = p.win_y0 + ty * 8u + (pix >> 3);
+  uint32_t tx0, ty0;
+  tile_origin(p, tile, tx0, ty0);
+  const uint32_t px = tx0 + (pix & 7u), py = ty0 + (pix >> 3);
   if (px >= p.win_x0 + p.win_w || py >= p.win_y0 + p.win_h) return;
   double r = 0.0, g = 0.0, b = 0.0, n = 0.0;
   for (uint32_t k = 0; k < w.R; ++k) {

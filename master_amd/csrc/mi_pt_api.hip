@@ -40,6 +40,7 @@ struct mi_pt_handle {
   uint64_t* d_morton = nullptr;
   mi_bvh_info info{};
   int kernel_choice = MI_PT_KERNEL_AUTO;
+  uint32_t shard_rank = 0, shard_world = 1;  // mi_pt_set_tile_shard
   bool instrumented = false;
   bool lds_fits = false;
   double* partial = nullptr; size_t partial_bytes = 0;
@@ -368,6 +369,13 @@ int mi_pt_set_kernel(mi_pt_handle* h, int kernel) {
   h->kernel_choice = kernel;
   return MI_OK;
 }
+int mi_pt_set_tile_shard(mi_pt_handle* h, uint32_t rank, uint32_t world) {
+  if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "null handle");
+  if (world <= 1) { h->shard_rank = 0; h->shard_world = 1; return MI_OK; }
+  if (rank >= world) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_set_tile_shard: rank must be < world");
+  h->shard_rank = rank; h->shard_world = world;
+  return MI_OK;
+}
 int mi_pt_set_instrumented(mi_pt_handle* h, int on) {
   if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "null handle");
   h->instrumented = on != 0;
@@ -396,7 +404,19 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
 
   p.win_x0 = win.x0; p.win_y0 = win.y0; p.win_w = win.w; p.win_h = win.h;
   p.tiles_x = (win.w + 7) / 8; p.tiles_y = (win.h + 7) / 8;
+  const bool sharded = h->shard_world > 1;
+  if (sharded) {  // this rank's 32x32 tiles (Technique.cpp:167) of the window, 16 wave tiles each; a rank may own none
+    const uint64_t mtx = (uint64_t(win.w) + 31) / 32, mty = (uint64_t(win.h) + 31) / 32, mt = mtx * mty;
+    const uint64_t owned = mt > h->shard_rank ? (mt - h->shard_rank + h->shard_world - 1) / h->shard_world : 0;
+    p.shard_rank = h->shard_rank; p.shard_world = h->shard_world; p.shard_mtx = uint32_t(mtx);
+    p.tiles_x = uint32_t(owned * 16); p.tiles_y = 1;
+  }
   const uint64_t n_tiles = uint64_t(p.tiles_x) * p.tiles_y;
+  if (n_tiles == 0) {  // nothing owned: the framebuffer is all zeros
+    HIP_TRY(hipMemsetAsync(rgbn_sum_device, 0, size_t(width) * height * 16, stream));
+    if (stats) { HIP_TRY(hipStreamSynchronize(stream)); std::memset(stats, 0, sizeof *stats); }
+    return MI_OK;
+  }
   if (h->kernel_choice == MI_PT_KERNEL_WAVEFRONT) {
     // slot i = pixel slot i % per_sample, replica i / per_sample: R replicas of every pixel are in flight
     const uint64_t per_sample = n_tiles * 64ull;
@@ -461,6 +481,7 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
   p.counters = h->d_counters;
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(h->ev0, stream));
+  if (sharded) HIP_TRY(hipMemsetAsync(h->partial, 0, size_t(p.n_chunks) * width * height * 32, stream));  // pixels of other ranks' tiles
   HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), false, h->instrumented, uint32_t(n_blocks), stream));
   HIP_TRY(hipEventRecord(h->ev1, stream));
   HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
@@ -666,6 +687,7 @@ int mi_bpt_set_sky(mi_pt_handle* h, const float horizon[3], const float zenith[3
 int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint64_t seed,
                   uint64_t sample_offset, float* rgbn_sum, mi_pt_stats* stats) {
   if (!h || !rgbn_sum) return fail(MI_ERR_INVALID_ARGUMENT, "mi_bpt_render: null argument");
+  if (h->shard_world > 1) return fail(MI_ERR_UNSUPPORTED, "mi_bpt_render: light-image splats cross tiles; shard BPT by sample ranges (sample_offset)");
   if (spp == 0) return fail(MI_ERR_INVALID_ARGUMENT, "spp must be > 0");
   if (win.w == 0 || win.h == 0) { win.x0 = 0; win.y0 = 0; win.w = width; win.h = height; }
   if (uint64_t(win.x0) + win.w > width || uint64_t(win.y0) + win.h > height)

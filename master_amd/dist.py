@@ -7,7 +7,15 @@ random stream is keyed on the GLOBAL sample index, so rank r of R renders the sa
 `master merge` does with EXRs from different machines (merge_exr, Options.cpp:1340-1409:
 dst = fst + snd on (R, G, B, denom)).  The sum is one RCCL all-reduce over xGMI
 (torch.distributed backend "nccl" on ROCm) or gloo on CPU tensors in the tests.
+
+The second decomposition (BASELINE config C5) shards PIXELS: the window is cut
+into the 32x32 tiles of Technique::_trace_paths (Technique.cpp:167), rank r owns the tiles
+{t : t mod R == r} (mi_pt_set_tile_shard) and renders ALL samples of them; the other pixels are
+zeros, so the same sum-reduce acts as a gather and the merged image is bit-identical to the
+one-GPU render (one FP64 accumulation per pixel, on its owner).
 """
+
+TILE = 32  # exec2d tile size, Technique.cpp:167
 
 
 def sample_offset(step, rank, world_size, spp_per_rank):
@@ -27,3 +35,22 @@ def merge_framebuffers(fb, group=None, dst=None):
     else:
         dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return fb
+
+
+def tile_owner(width, height, world_size, window=None):
+    """[h][w] int array: the rank that owns each pixel of the window under pixel-tile sharding
+    (tiles numbered row-major from the window's origin, row 0 = bottom like the framebuffer)."""
+    import numpy as np
+
+    x0, y0, w, h = window if window else (0, 0, width, height)
+    ty, tx = np.meshgrid(np.arange(h) // TILE, np.arange(w) // TILE, indexing="ij")
+    owner = np.full((height, width), -1, dtype=np.int64)
+    owner[y0:y0 + h, x0:x0 + w] = (ty * ((w + TILE - 1) // TILE) + tx) % max(world_size, 1)
+    return owner
+
+
+def tile_sample_range(step, world_size, spp_per_rank):
+    """(sample_offset, spp) every rank renders on ITS tiles in `step` under pixel-tile sharding: each rank has
+    1/world of the pixels and renders world x spp_per_rank samples of them (weak scaling: work per rank fixed)."""
+    n = world_size * spp_per_rank
+    return step * n, n

@@ -45,6 +45,62 @@ def _worker(rank, world, port, spp, steps, out_dir):
     dist.destroy_process_group()
 
 
+def _tile_worker(rank, world, port, spp, steps, out_dir):
+    """Pixel-tile sharding (BASELINE C5): the rank renders ALL samples of its 32x32 tiles, zeros elsewhere."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import master_amd as ma
+    import oracle
+    from master_amd import dist as madist
+
+    W, H = 72, 40
+    scene = ma.Scene.load(scene_path("CornellBoxDiffuse"))
+    orc = oracle.Oracle(scene, max_path=4)
+    mine = madist.tile_owner(W, H, world) == rank
+    total = torch.zeros((H, W, 4), dtype=torch.float32)
+    for step in range(steps):
+        off, n = madist.tile_sample_range(step, world, spp)
+        full = orc.render_rgbn(W, H, spp=n, seed=5, sample_offset=off, threads=1)  # stand-in for the device's sharded render:
+        fb = torch.from_numpy(np.where(mine[..., None], full, np.float32(0)))       # what mi_pt_set_tile_shard leaves in the framebuffer
+        madist.merge_framebuffers(fb)
+        total += fb
+    np.save(os.path.join(out_dir, "tiles_%d.npy" % rank), total.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_owners_partition_the_window():
+    from master_amd import dist as madist
+
+    for world in (1, 2, 3, 8):
+        for (W, H, win) in ((72, 40, None), (100, 70, (5, 3, 66, 64)), (31, 31, None)):
+            own = madist.tile_owner(W, H, world, win)
+            x0, y0, w, h = win if win else (0, 0, W, H)
+            inside = np.zeros((H, W), bool); inside[y0:y0 + h, x0:x0 + w] = True
+            assert ((own >= 0) == inside).all() and own.max() < world
+            # tiles are 32x32 blocks counted from the window's origin, row-major, dealt round-robin
+            assert own[y0, x0] == 0
+            if w > 32:
+                assert own[y0, x0 + 32] == 1 % world and own[y0 + min(31, h - 1), x0 + 31] == 0
+            if h > 32:
+                assert own[y0 + 32, x0] == ((w + 31) // 32) % world
+    assert madist.tile_sample_range(2, 8, 16) == (256, 128)
+
+
+def test_world2_gloo_tile_sharding_is_bit_identical_to_one_process(tmp_path):
+    world, spp, steps = 2, 2, 2
+    mp.spawn(_tile_worker, args=(world, _free_port(), spp, steps, str(tmp_path)), nprocs=world, join=True)
+    import master_amd as ma
+    import oracle
+
+    scene = ma.Scene.load(scene_path("CornellBoxDiffuse"))
+    orc = oracle.Oracle(scene, max_path=4)
+    single = sum(orc.render_rgbn(72, 40, spp=spp * world, seed=5, sample_offset=s * spp * world, threads=1) for s in range(steps))
+    t0, t1 = np.load(tmp_path / "tiles_0.npy"), np.load(tmp_path / "tiles_1.npy")
+    assert np.array_equal(t0, t1) and np.array_equal(t0, single)  # every pixel has one owner: the reduce only adds zeros
+
+
 def test_sample_offsets_partition_the_sample_axis():
     from master_amd import dist as madist
 

@@ -402,6 +402,39 @@ def test_4k_frame_and_window_against_oracle(cornell):
     assert (pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays) == (orc.last_stats.num_basic_rays, orc.last_stats.num_shadow_rays)
 
 
+@pytest.mark.parametrize("kernel", [ma.KERNEL_MEGA_LDS, ma.KERNEL_MEGA_GLOBAL, ma.KERNEL_WAVEFRONT])
+def test_pixel_tile_sharding_is_a_bitwise_partition_of_the_render(cornell, kernel):
+    """mi_pt_set_tile_shard (BASELINE C5 / SURVEY 8(e)(ii)): rank r renders the 32x32 tiles {t : t mod R == r}, zeros
+    elsewhere; each rank's framebuffer is the unsharded one under its mask, so the ranks' sum (merge_exr) IS the render."""
+    from master_amd import dist as madist
+
+    pt = ma.PathTracing(cornell, max_path=8)
+    pt.set_kernel(kernel)
+    for (W, H, win) in ((200, 136, None), (200, 136, (13, 7, 150, 100)), (24, 24, None)):
+        full = pt.render_rgbn(W, H, spp=6, seed=9, sample_offset=4, window=win)
+        full_stats = (pt.last_stats.num_paths, pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays)
+        for world in (2, 3, 8):
+            own = madist.tile_owner(W, H, world, win)
+            acc = np.zeros_like(full)
+            stats = np.zeros(3, np.int64)
+            for rank in range(world):
+                pt.set_tile_shard(rank, world)
+                fb = pt.render_rgbn(W, H, spp=6, seed=9, sample_offset=4, window=win)
+                mine = own == rank
+                assert np.array_equal(fb.view(np.uint32), np.where(mine[..., None], full, np.float32(0)).view(np.uint32)), (W, H, win, world, rank)
+                assert pt.last_stats.num_paths == int(mine.sum()) * 6
+                stats += (pt.last_stats.num_paths, pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays)
+                acc += fb
+            assert np.array_equal(acc, full) and tuple(stats) == full_stats
+        pt.set_tile_shard(0, 1)
+        assert np.array_equal(pt.render_rgbn(W, H, spp=6, seed=9, sample_offset=4, window=win), full)
+    with pytest.raises(ma.MiError):
+        pt.set_tile_shard(2, 2)
+    pt.set_tile_shard(1, 2)
+    with pytest.raises(ma.MiError, match="sample ranges"):
+        pt.bpt_render_rgbn(32, 32, spp=1)
+
+
 def test_degenerate_and_coincident_triangles():
     """Zero-area triangles are never hit (den == 0); coincident triangles tie on t and the smaller global index wins —
     on the device (BVH order) exactly as in the oracle (index order)."""

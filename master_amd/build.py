@@ -26,7 +26,7 @@ SOURCES = [
 
 HEADERS = [
     "../../include/mi_pt.h", "scene_host.hpp", "device/layout.h", "device/launch.h", "device/pt_device.h",
-    "device/rng.h", "device/vecmath.h",
+    "device/rng.h", "device/vecmath.h", "device/bpt.h", "device/wavefront.h",
 ]
 
 

@@ -458,8 +458,14 @@ MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, TravStack
 }  // namespace
 
 // ---- stage A ----
+#ifndef MI_BPT_TRACE_WAVES
+#define MI_BPT_TRACE_WAVES 4
+#endif
+#ifndef MI_BPT_ITEMS_WAVES
+#define MI_BPT_ITEMS_WAVES 6  // tools/ab_bpt_stage_waves.sh, 512^2 x 32: items 3/4/5/6 waves = 53.9/56.6/54.4/55.4 ms (Cornell), 280/281/282/272 ms (LivingRoomLit);
+#endif                        // trace 3/4/5 waves = 61.4/56.6/62.4 and 303/281/286 ms
 template <bool LIST, int QN>
-__global__ __launch_bounds__(kBlock, 4) void bpt_trace(const RenderParams p, const BptState w) {
+__global__ __launch_bounds__(kBlock, MI_BPT_TRACE_WAVES) void bpt_trace(const RenderParams p, const BptState w) {
   extern __shared__ float4 smem[];
   SceneView sv = p.sv;
   const float4* sb = sv.blob;
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(256) void bpt_scan_add(uint32_t* __restrict__ data,
 
 // ---- stage B: one lane per connection item ----
 template <bool LIST, int QN>
-__global__ __launch_bounds__(kBlock, 4) void bpt_items(const RenderParams p, const BptState w, uint32_t item_first, uint32_t item_count) {
+__global__ __launch_bounds__(kBlock, MI_BPT_ITEMS_WAVES) void bpt_items(const RenderParams p, const BptState w, uint32_t item_first, uint32_t item_count) {
   extern __shared__ float4 smem[];
   SceneView sv = p.sv;
   const float4* sb = sv.blob;

@@ -191,6 +191,21 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
  * The other way to shard, by sample ranges, needs no call: see sample_offset above. */
 int mi_pt_set_tile_shard(mi_pt_handle* h, uint32_t rank, uint32_t world);
 
+/* Several GPUs from ONE host process — the reference is a single process whose Technique::_trace_paths
+ * (Technique.cpp:163-192) deals 32x32 tiles to the threads of its pool (exec2d, threadpool.cpp:190-233); here the
+ * same tiles are dealt to `n_handles` handles created from the same scene on different devices
+ * (tile t goes to handle t mod n_handles, like mi_pt_set_tile_shard).  All devices render concurrently on
+ * their own streams; the caller's framebuffer receives every tile from its owner, so the result is
+ * bit-identical to mi_pt_render on one handle, also at spp = 1 per call (the cadence of Application::render,
+ * Application.cpp:66).  `stats` receives the sums of the ray / path / error counts and the slowest device's
+ * times.  Any tile shard set on the handles is ignored for the call and restored afterwards. */
+int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_t camera_id, uint32_t width,
+                       uint32_t height, mi_window win, uint32_t spp, uint64_t seed, uint64_t sample_offset,
+                       float* rgbn_sum, mi_pt_stats* stats);
+
+/* Number of HIP devices visible to the process (0 without a GPU; never fails). */
+int mi_pt_device_count(void);
+
 /* Replaces: reading the message of std::logic_error / std::runtime_error thrown by the
  * reference (runtime_assert.cpp:7-11).  Thread-local, never NULL. */
 const char* mi_pt_last_error(void);

@@ -68,11 +68,18 @@ GpuPathTracing::GpuPathTracing(const shared<const Scene>& scene, float lights, f
   d.mesh_tri_offset = offsets.data(); d.mesh_material_id = mesh_material.data();
   d.materials = materials.data(); d.lights = mlights.data(); d.cameras = cams.data();
   mi_pt_params p = {uint64_t(max_path), beta, roulette, lights, 3};
-  check(mi_pt_create(&d, &p, device, &_handle));          // copies the scene, builds the BVH on the GPU; a zero bounding_sphere is computed as loader.cpp:408-432
+  // copies the scene, builds the BVH on the GPU; a zero bounding_sphere is computed as loader.cpp:408-432
+  const int first = device < 0 ? 0 : device, count = device < 0 && !bidirectional ? mi_pt_device_count() : 1;
+  for (int k = 0; k < (count > 0 ? count : 1); ++k) {
+    mi_pt_handle* h = nullptr;
+    check(mi_pt_create(&d, &p, first + k, &h));
+    _handles.push_back(h);
+  }
+  _handle = _handles[0];
   _seed = std::random_device()();                          // like Sample.inl:249-252: PT is not seedable
 }
 
-GpuPathTracing::~GpuPathTracing() { mi_pt_destroy(_handle); }
+GpuPathTracing::~GpuPathTracing() { for (mi_pt_handle* h : _handles) mi_pt_destroy(h); }
 
 void GpuPathTracing::render(subimage_view_t& view, RandomEngine&, size_t cameraId, const vector<vec3>& reference,
                             const vector<ivec3>& trace_points) {
@@ -88,6 +95,9 @@ void GpuPathTracing::render(subimage_view_t& view, RandomEngine&, size_t cameraI
   if (_bidirectional)  // light-image splats land anywhere; light + eye are committed per frame inside, for the window only
     check(mi_bpt_render(_handle, uint32_t(cameraId), uint32_t(view.width()), uint32_t(view.height()), win,
                         /*spp=*/1, _seed, /*sample_offset=*/_statistics.num_samples, _rgbn.data(), &st));
+  else if (_handles.size() > 1)  // one frame, its tiles dealt to all GPUs of this process; bit-identical to one GPU
+    check(mi_pt_render_multi(_handles.data(), uint32_t(_handles.size()), uint32_t(cameraId), uint32_t(view.width()), uint32_t(view.height()), win,
+                             /*spp=*/1, _seed, /*sample_offset=*/_statistics.num_samples, _rgbn.data(), &st));
   else
     check(mi_pt_render(_handle, uint32_t(cameraId), uint32_t(view.width()), uint32_t(view.height()), win,
                        /*spp=*/1, _seed, /*sample_offset=*/_statistics.num_samples, _rgbn.data(), &st));

@@ -110,7 +110,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 # every symbol include/mi_pt.h declares; tests/test_abi.py checks the library exports them all
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version",
-    "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_tile_shard", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
+    "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_tile_shard", "mi_pt_render_multi", "mi_pt_device_count", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
     "mi_bpt_render", "mi_bpt_trace_paths", "mi_bpt_set_sky",
     "mi_pt_bvh_download", "mi_pt_blob_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
     "mi_scene_load", "mi_scene_save", "mi_scene_from_desc", "mi_scene_get_desc", "mi_scene_material_name", "mi_scene_mesh_name",
@@ -137,6 +137,8 @@ def lib():
     L.mi_pt_render_device.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, vp, C.POINTER(PtStats)]
     L.mi_pt_set_kernel.argtypes = [vp, C.c_int]
     L.mi_pt_set_tile_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.mi_pt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, Window, C.c_uint32, C.c_uint64, C.c_uint64, vp, C.POINTER(PtStats)]
+    L.mi_pt_device_count.restype = C.c_int
     L.mi_pt_get_kernel.argtypes = [vp]
     L.mi_pt_set_instrumented.argtypes = [vp, C.c_int]
     L.mi_pt_intersect.argtypes = [vp, u32, vp, vp, vp, vp, vp]
@@ -337,6 +339,21 @@ def load_exr(path):
         return np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
     finally:
         lib().mi_free(p)
+
+
+def device_count():
+    return lib().mi_pt_device_count()
+
+
+def render_multi(techniques, width, height, spp=1, seed=0, sample_offset=0, camera_id=0, window=None):
+    """mi_pt_render_multi: one frame set rendered by several PathTracing handles (one per GPU) of ONE process; the 32x32
+    tiles of Technique::_trace_paths (Technique.cpp:167) are dealt round-robin to the handles.  Returns (rgbn, stats)."""
+    out = np.zeros((height, width, 4), dtype=np.float32)
+    st = PtStats()
+    win = Window(*window) if window else Window(0, 0, 0, 0)
+    hs = (C.c_void_p * len(techniques))(*[t._h.value for t in techniques])
+    _check(lib().mi_pt_render_multi(hs, len(techniques), camera_id, width, height, win, spp, seed, sample_offset, _ptr(out), C.byref(st)))
+    return out, st
 
 
 class PathTracing:

@@ -45,6 +45,7 @@ struct mi_pt_handle {
   bool lds_fits = false;
   double* partial = nullptr; size_t partial_bytes = 0;
   float* d_rgbn = nullptr; size_t rgbn_bytes = 0;
+  float* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned host copy of d_rgbn (mi_pt_render_multi)
   unsigned long long* d_counters = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -358,6 +359,7 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->d_counters) hipFree(h->d_counters);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->h_stage) hipHostFree(h->h_stage);
   if (h->ev2) hipEventDestroy(h->ev2);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -386,6 +388,24 @@ int mi_pt_get_kernel(mi_pt_handle* h) {
   if (h->kernel_choice == MI_PT_KERNEL_WAVEFRONT) return MI_PT_KERNEL_WAVEFRONT;
   return use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
 }
+
+namespace {
+// counters and event times of the megakernel launch last recorded on `stream` (waits for it)
+int collect_stats(mi_pt_handle* h, hipStream_t stream, mi_pt_stats* stats) {
+  unsigned long long c[24];
+  HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  float t01 = 0.0f, t02 = 0.0f;
+  HIP_TRY(hipEventElapsedTime(&t01, h->ev0, h->ev1));
+  HIP_TRY(hipEventElapsedTime(&t02, h->ev0, h->ev2));
+  stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
+  stats->trace_ms = t01; stats->gpu_ms = t02;
+  stats->nodes_closest = c[4]; stats->tris_closest = c[5]; stats->nodes_shadow = c[6]; stats->tris_shadow = c[7]; stats->num_hits = c[8]; stats->wave_steps_closest = c[9]; stats->wave_steps_shadow = c[10];
+  for (int k = 0; k < 8; ++k) stats->phase_cycles[k] = c[16 + k];
+  for (int k = 0; k < 4; ++k) stats->wave_loop_bodies[k] = c[11 + k];
+  return MI_OK;
+}
+}  // namespace
 
 int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp,
                         uint64_t seed, uint64_t sample_offset, float* rgbn_sum_device, void* stream_v, mi_pt_stats* stats) {
@@ -486,19 +506,7 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
   HIP_TRY(hipEventRecord(h->ev1, stream));
   HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
   HIP_TRY(hipEventRecord(h->ev2, stream));
-  if (stats) {
-    unsigned long long c[24];
-    HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    float t01 = 0.0f, t02 = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&t01, h->ev0, h->ev1));
-    HIP_TRY(hipEventElapsedTime(&t02, h->ev0, h->ev2));
-    stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
-    stats->trace_ms = t01; stats->gpu_ms = t02;
-    stats->nodes_closest = c[4]; stats->tris_closest = c[5]; stats->nodes_shadow = c[6]; stats->tris_shadow = c[7]; stats->num_hits = c[8]; stats->wave_steps_closest = c[9]; stats->wave_steps_shadow = c[10];
-    for (int k = 0; k < 8; ++k) stats->phase_cycles[k] = c[16 + k];
-    for (int k = 0; k < 4; ++k) stats->wave_loop_bodies[k] = c[11 + k];
-  }
+  if (stats) return collect_stats(h, stream, stats);
   return MI_OK;
 }
 
@@ -514,6 +522,85 @@ int mi_pt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t h
   rc = mi_pt_render_device(h, camera_id, width, height, win, spp, seed, sample_offset, h->d_rgbn, nullptr, stats ? stats : &local);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(rgbn_sum, h->d_rgbn, bytes, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_pt_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win,
+                       uint32_t spp, uint64_t seed, uint64_t sample_offset, float* rgbn_sum, mi_pt_stats* stats) {
+  if (!handles || n_handles == 0 || !rgbn_sum) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_multi: null argument");
+  for (uint32_t k = 0; k < n_handles; ++k) {
+    if (!handles[k]) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_multi: null handle");
+    for (uint32_t j = 0; j < k; ++j) if (handles[j] == handles[k]) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_multi: a handle is listed twice");
+  }
+  if (width == 0 || height == 0 || uint64_t(width) * height > (1ull << 31)) return fail(MI_ERR_INVALID_ARGUMENT, "bad resolution");
+  if (win.w == 0 || win.h == 0) { win.x0 = 0; win.y0 = 0; win.w = width; win.h = height; }
+  if (uint64_t(win.x0) + win.w > width || uint64_t(win.y0) + win.h > height)
+    return fail(MI_ERR_INVALID_ARGUMENT, "window exceeds the image");  // Technique.cpp:318-319 runtime_assert
+  const size_t bytes = size_t(width) * height * 16;
+  // 1. every device renders its tiles on its own stream and copies its framebuffer to pinned host memory
+  int rc = MI_OK;
+  uint32_t launched = 0;
+  for (; launched < n_handles && rc == MI_OK; ++launched) {
+    mi_pt_handle* h = handles[launched];
+    rc = hipSetDevice(h->device) == hipSuccess ? MI_OK : fail(MI_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (rc == MI_OK) rc = ensure(reinterpret_cast<void**>(&h->d_rgbn), &h->rgbn_bytes, bytes);
+    if (rc == MI_OK && h->h_stage_bytes < bytes) {
+      if (h->h_stage) hipHostFree(h->h_stage);
+      h->h_stage = nullptr; h->h_stage_bytes = 0;
+      if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), bytes, hipHostMallocDefault) != hipSuccess) rc = fail(MI_ERR_OUT_OF_MEMORY, "pinned host staging buffer");
+      else h->h_stage_bytes = bytes;
+    }
+    if (rc != MI_OK) break;
+    const uint32_t saved_rank = h->shard_rank, saved_world = h->shard_world;
+    h->shard_rank = launched; h->shard_world = n_handles;
+    rc = mi_pt_render_device(h, camera_id, width, height, win, spp, seed, sample_offset, h->d_rgbn, nullptr, nullptr);  // asynchronous
+    h->shard_rank = saved_rank; h->shard_world = saved_world;
+    if (rc == MI_OK && hipMemcpyAsync(h->h_stage, h->d_rgbn, bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(MI_ERR_NO_DEVICE, "framebuffer copy failed");
+  }
+  // 2. wait for every device that was started, also after an error
+  mi_pt_stats total; std::memset(&total, 0, sizeof total);
+  for (uint32_t k = 0; k < launched; ++k) {
+    mi_pt_handle* h = handles[k];
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { if (rc == MI_OK) rc = fail(MI_ERR_NO_DEVICE, "device synchronisation failed"); continue; }
+    if (rc != MI_OK || !stats) continue;
+    const uint64_t mtx = (uint64_t(win.w) + 31) / 32, mt = mtx * ((uint64_t(win.h) + 31) / 32);
+    if (mt <= k) continue;  // this handle owned no tile: nothing was launched on it
+    mi_pt_stats one; std::memset(&one, 0, sizeof one);
+    if (h->kernel_choice == MI_PT_KERNEL_WAVEFRONT) {  // the pipeline has no per-launch record to read back: counts only
+      unsigned long long c[24];
+      if (hipMemcpy(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MI_ERR_NO_DEVICE, "counter copy failed"); continue; }
+      one.num_basic_rays = c[0]; one.num_shadow_rays = c[1]; one.numeric_errors = c[2]; one.num_paths = c[3];
+    } else {
+      const int r2 = collect_stats(h, h->stream, &one);
+      if (r2 != MI_OK) { rc = r2; continue; }
+    }
+    total.num_basic_rays += one.num_basic_rays; total.num_shadow_rays += one.num_shadow_rays; total.numeric_errors += one.numeric_errors;
+    total.num_paths += one.num_paths; total.nodes_closest += one.nodes_closest; total.tris_closest += one.tris_closest;
+    total.nodes_shadow += one.nodes_shadow; total.tris_shadow += one.tris_shadow; total.num_hits += one.num_hits;
+    total.wave_steps_closest += one.wave_steps_closest; total.wave_steps_shadow += one.wave_steps_shadow;
+    for (int j = 0; j < 8; ++j) total.phase_cycles[j] += one.phase_cycles[j];
+    for (int j = 0; j < 4; ++j) total.wave_loop_bodies[j] += one.wave_loop_bodies[j];
+    if (one.trace_ms > total.trace_ms) total.trace_ms = one.trace_ms;
+    if (one.gpu_ms > total.gpu_ms) total.gpu_ms = one.gpu_ms;
+  }
+  if (rc != MI_OK) return rc;
+  // 3. every 32x32 tile of the window from its owner; everything else is zero
+  std::memset(rgbn_sum, 0, bytes);
+  const uint32_t mtx = (win.w + 31) / 32, mty = (win.h + 31) / 32;
+  for (uint32_t ty = 0; ty < mty; ++ty)
+    for (uint32_t tx = 0; tx < mtx; ++tx) {
+      const float* src = handles[(uint64_t(ty) * mtx + tx) % n_handles]->h_stage;
+      const uint32_t x0 = win.x0 + tx * 32, x1 = x0 + 32 < win.x0 + win.w ? x0 + 32 : win.x0 + win.w;
+      const uint32_t y0 = win.y0 + ty * 32, y1 = y0 + 32 < win.y0 + win.h ? y0 + 32 : win.y0 + win.h;
+      for (uint32_t y = y0; y < y1; ++y)
+        std::memcpy(rgbn_sum + (size_t(y) * width + x0) * 4, src + (size_t(y) * width + x0) * 4, size_t(x1 - x0) * 16);
+    }
+  if (stats) *stats = total;
   return MI_OK;
 }
 

@@ -130,3 +130,18 @@ def test_c_example_renders_and_writes_the_reference_exr_layout(tmp_path, techniq
     img = ma.load_exr(out)
     assert img.shape == (96, 96, 4) and np.all(img[..., 3] == 64)
     assert abs(float((img[..., :3] / img[..., 3:]).mean()) - 1.0) < 0.03  # a normalised model of the reference
+
+
+@pytest.mark.gpu
+def test_c_example_on_several_devices_writes_the_same_image(tmp_path):
+    """--gpus 3: mi_pt_render_multi from plain C (handles share this box's GPU); the EXR equals the one-handle render bit for bit."""
+    import subprocess
+    exe, root = _build_c_example(tmp_path)
+    outs = []
+    for gpus in ("1", "3"):
+        out = str(tmp_path / ("o%s.exr" % gpus))
+        r = subprocess.run([exe, os.path.join(root, "scenes", "CornellBoxDiffuse.miscene"), out, "--spp", "8", "--size", "100x72", "--max-path", "6", "--gpus", gpus],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(ma.load_exr(out))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))

@@ -435,6 +435,29 @@ def test_pixel_tile_sharding_is_a_bitwise_partition_of_the_render(cornell, kerne
         pt.bpt_render_rgbn(32, 32, spp=1)
 
 
+@pytest.mark.parametrize("kernel", [ma.KERNEL_AUTO, ma.KERNEL_MEGA_GLOBAL, ma.KERNEL_WAVEFRONT])
+def test_one_process_multi_device_render_is_bit_identical(cornell, kernel):
+    """mi_pt_render_multi: several handles (one per GPU; here all on this box's only GPU, on their own streams) render the
+    tiles of one frame set concurrently; the merged framebuffer and the summed statistics equal one handle's render."""
+    assert ma.device_count() >= 1
+    pts = [ma.PathTracing(cornell, max_path=8) for _ in range(3)]
+    for t in pts:
+        t.set_kernel(kernel)
+    pts[1].set_tile_shard(1, 2)  # a shard set on a handle is ignored for the call and restored
+    for (W, H, win, spp) in ((200, 136, None, 5), (200, 136, (13, 7, 150, 100), 1), (24, 24, None, 2)):
+        ref = pts[0].render_rgbn(W, H, spp=spp, seed=11, sample_offset=3, window=win)
+        rs = pts[0].last_stats
+        for n in (1, 2, 3):
+            img, st = ma.render_multi(pts[:n], W, H, spp=spp, seed=11, sample_offset=3, window=win)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (W, H, win, n)
+            assert (st.num_paths, st.num_basic_rays, st.num_shadow_rays, st.numeric_errors) == (rs.num_paths, rs.num_basic_rays, rs.num_shadow_rays, rs.numeric_errors)
+            assert kernel == ma.KERNEL_WAVEFRONT or st.gpu_ms > 0
+    own = pts[1].render_rgbn(64, 64, spp=1, seed=1)   # still sharded (1 of 2): the left 32 columns of the upper tile row... belong to rank 0
+    assert (own[:32, :32, 3] == 0).all() and (own[:32, 32:, 3] == 1).all()
+    with pytest.raises(ma.MiError):
+        ma.render_multi([pts[0], pts[0]], 32, 32)
+
+
 def test_degenerate_and_coincident_triangles():
     """Zero-area triangles are never hit (den == 0); coincident triangles tie on t and the smaller global index wins —
     on the device (BVH order) exactly as in the oracle (index order)."""

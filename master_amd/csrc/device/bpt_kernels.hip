@@ -33,7 +33,7 @@ MI_DEV float betaf(const Ctx& c, float x) {  // Beta.hpp:24-41
   if (c.beta == 0.0f) return x == 0.0f ? 0.0f : 1.0f;
   if (c.beta == 1.0f) return x;
   if (c.beta == 2.0f) return x * x;
-  return powf(x, c.beta);
+  return mi_powf(x, c.beta);
 }
 
 // ---- Sample.inl:5-37 angular_bound, :121-133 lambert_adjust ----

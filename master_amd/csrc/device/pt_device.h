@@ -314,7 +314,7 @@ MI_DEV BQuery phong_query_local(const Material& m, f3 incident, f3 outgoing, flo
   const f3 reflected = F3(-incident.x, incident.y, -incident.z);
   float ca = dot(outgoing, reflected);
   ca = ca < 0.0f ? 0.0f : (ca > 1.0f ? 1.0f : ca);
-  const float cap = powf(ca, m.power);
+  const float cap = mi_powf(ca, m.power);
   const float sd = (m.power + 1.0f) * half_over_pi * cap;
   const f3 specular = ((m.specular * (m.power + 2.0f)) * half_over_pi) * cap;
   BQuery q;
@@ -353,7 +353,7 @@ MI_DEV f3 sample_phong(Rng& g, f3 omega, float power) {
   m.c1 = F3(-omega.x, omega.y, -omega.z);
   m.c2 = normalize(F3(0.0f, 1.0f, 0.0f) - m.c1 * m.c1.y);
   m.c0 = normalize(cross(m.c1, m.c2));
-  const float y = powf(rng_f(g), 1.0f / (power + 1.0f));
+  const float y = mi_powf(rng_f(g), 1.0f / (power + 1.0f));
   const float r = sqrtf(1.0f - y * y);
   float sn, cs;
   sincos_2pi(rng_f(g), &sn, &cs);
@@ -415,7 +415,7 @@ MI_DEV void query_lsdf(const float4* __restrict__ sb, const SceneView& sv, uint3
   density = l5.x;
 }
 
-MI_DEV float powb(float x, float beta) { return beta == 1.0f ? x : (beta == 2.0f ? x * x : powf(x, beta)); }
+MI_DEV float powb(float x, float beta) { return beta == 1.0f ? x : (beta == 2.0f ? x * x : mi_powf(x, beta)); }
 
 // PathTracing::_connect (PT.cpp:100-120) incl. AreaLights::sample (AreaLights.cpp:121-140,216-231),
 // LightBSDF::query / sun_light_bsdf::query (BSDF.cpp:95-114,181-191; only .throughput is used) and

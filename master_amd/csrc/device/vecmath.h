@@ -98,4 +98,63 @@ MI_DEV void mi_sincosf(float rad, float* s, float* c) {
   sincos_2pi(t - floorf(t), s, c);
 }
 
+// pow(x, y) of the Phong lobe and of the MIS weights with a variable beta: DEFINED in the oracle (2^(y log2 x) in FP64, every step a
+// single IEEE operation or an explicit fma, one rounding to FP32) and stated identically here, so Phong scenes are bit-exact too.
+#define MI_D2U(d) ((uint64_t)__double_as_longlong(d))
+#define MI_U2D(u) __longlong_as_double((long long)(u))
+MI_DEV float mi_powf(float x, float y) {
+  if (y == 0.0f || x == 1.0f) return 1.0f;
+  if (x != x || y != y) return x + y;
+  const float ax = fabsf(x), ay = fabsf(y);
+  const int y_int = floorf(y) == y;
+  const int y_odd = y_int && ay < 16777216.0f && (((int)y) & 1);
+  const int neg = x < 0.0f;
+  if (neg && !y_int) return __builtin_nanf("");
+  float r;
+  if (ax == 1.0f) r = 1.0f;
+  else if (ax == 0.0f) r = y > 0.0f ? 0.0f : __builtin_inff();
+  else if (ax == __builtin_inff()) r = y > 0.0f ? __builtin_inff() : 0.0f;
+  else if (ay == __builtin_inff()) r = ((ax < 1.0f) == (y > 0.0f)) ? 0.0f : __builtin_inff();
+  else {
+    /* log2(ax): ax = m * 2^e, m in (sqrt(1/2), sqrt(2)]; ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716 */
+    const uint64_t u = MI_D2U((double)ax);
+    int e = (int)(u >> 52) - 1023;
+    double m = MI_U2D((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = fma(0.11764705882352941, z, 0.13333333333333333);
+    p = fma(p, z, 0.15384615384615385);
+    p = fma(p, z, 0.18181818181818182);
+    p = fma(p, z, 0.22222222222222221);
+    p = fma(p, z, 0.2857142857142857);
+    p = fma(p, z, 0.4);
+    p = fma(p, z, 0.66666666666666663);
+    const double ln_m = fma(s * z, p, s + s);
+    const double t = (double)y * fma(ln_m, 1.4426950408889634, (double)e);
+    /* 2^t: t = n + q, |q| <= 1/2, e^(q ln 2) by its Taylor polynomial of degree 12; float results below FLT_MIN are flushed */
+    if (t >= 128.0) r = __builtin_inff();
+    else if (t < -126.0) r = 0.0f;
+    else {
+      const double n = floor(t + 0.5);
+      const double w = (t - n) * 0.69314718055994531;
+      double c = fma(2.08767569878681e-9, w, 2.505210838544172e-8);
+      c = fma(c, w, 2.7557319223985888e-7);
+      c = fma(c, w, 2.7557319223985893e-6);
+      c = fma(c, w, 2.4801587301587302e-5);
+      c = fma(c, w, 1.9841269841269841e-4);
+      c = fma(c, w, 1.3888888888888889e-3);
+      c = fma(c, w, 8.3333333333333332e-3);
+      c = fma(c, w, 4.1666666666666664e-2);
+      c = fma(c, w, 0.16666666666666666);
+      c = fma(c, w, 0.5);
+      c = fma(c, w, 1.0);
+      c = fma(c, w, 1.0);
+      r = (float)(c * MI_U2D((uint64_t)(1023 + (int)n) << 52));
+    }
+  }
+  return neg && y_odd ? -r : r;
+}
+
 }  // namespace mi

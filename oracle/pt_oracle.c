@@ -162,6 +162,71 @@ static inline void mi_sincosf(float rad, float* s, float* c) {
   sincos_2pi(t - floorf(t), s, c);
 }
 
+/* pow(x, y) of the Phong lobe (BSDF.cpp:306-391, Sample.inl:139-151) and of the MIS weights with a variable beta (Beta.hpp:24-41).
+ * DEFINED here like the functions above (glibc's powf and the device library's differ in the last bit): 2^(y log2 x) in FP64, each
+ * step a single IEEE operation or an explicit fma, rounded once to FP32 — within 1 ulp of the exact power, so it is the reference's
+ * std::pow up to a rare last-bit tie.  Special cases follow C99 pow; results below FLT_MIN are zero (FTZ, main.cpp:70-71). */
+static inline uint64_t mi_d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static inline double mi_u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+#define MI_D2U(d) mi_d2u(d)
+#define MI_U2D(u) mi_u2d(u)
+static inline float mi_powf(float x, float y) {
+  if (y == 0.0f || x == 1.0f) return 1.0f;
+  if (x != x || y != y) return x + y;
+  const float ax = fabsf(x), ay = fabsf(y);
+  const int y_int = floorf(y) == y;
+  const int y_odd = y_int && ay < 16777216.0f && (((int)y) & 1);
+  const int neg = x < 0.0f;
+  if (neg && !y_int) return __builtin_nanf("");
+  float r;
+  if (ax == 1.0f) r = 1.0f;
+  else if (ax == 0.0f) r = y > 0.0f ? 0.0f : __builtin_inff();
+  else if (ax == __builtin_inff()) r = y > 0.0f ? __builtin_inff() : 0.0f;
+  else if (ay == __builtin_inff()) r = ((ax < 1.0f) == (y > 0.0f)) ? 0.0f : __builtin_inff();
+  else {
+    /* log2(ax): ax = m * 2^e, m in (sqrt(1/2), sqrt(2)]; ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716 */
+    const uint64_t u = MI_D2U((double)ax);
+    int e = (int)(u >> 52) - 1023;
+    double m = MI_U2D((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = fma(0.11764705882352941, z, 0.13333333333333333);
+    p = fma(p, z, 0.15384615384615385);
+    p = fma(p, z, 0.18181818181818182);
+    p = fma(p, z, 0.22222222222222221);
+    p = fma(p, z, 0.2857142857142857);
+    p = fma(p, z, 0.4);
+    p = fma(p, z, 0.66666666666666663);
+    const double ln_m = fma(s * z, p, s + s);
+    const double t = (double)y * fma(ln_m, 1.4426950408889634, (double)e);
+    /* 2^t: t = n + q, |q| <= 1/2, e^(q ln 2) by its Taylor polynomial of degree 12; float results below FLT_MIN are flushed */
+    if (t >= 128.0) r = __builtin_inff();
+    else if (t < -126.0) r = 0.0f;
+    else {
+      const double n = floor(t + 0.5);
+      const double w = (t - n) * 0.69314718055994531;
+      double c = fma(2.08767569878681e-9, w, 2.505210838544172e-8);
+      c = fma(c, w, 2.7557319223985888e-7);
+      c = fma(c, w, 2.7557319223985893e-6);
+      c = fma(c, w, 2.4801587301587302e-5);
+      c = fma(c, w, 1.9841269841269841e-4);
+      c = fma(c, w, 1.3888888888888889e-3);
+      c = fma(c, w, 8.3333333333333332e-3);
+      c = fma(c, w, 4.1666666666666664e-2);
+      c = fma(c, w, 0.16666666666666666);
+      c = fma(c, w, 0.5);
+      c = fma(c, w, 1.0);
+      c = fma(c, w, 1.0);
+      r = (float)(c * MI_U2D((uint64_t)(1023 + (int)n) << 52));
+    }
+  }
+  return neg && y_odd ? -r : r;
+}
+
+ORC_API void orc_powf(uint32_t n, const float* x, const float* y, float* out) { for (uint32_t i = 0; i < n; ++i) out[i] = mi_powf(x[i], y[i]); }
+
 /* ------------------------------------------------------------------ RNG (defined here) */
 typedef struct { uint64_t state; } rng_t;
 #define PCG_MULT 6364136223846793005ULL
@@ -627,7 +692,7 @@ static bq_t phong_query_local(const mi_material* m, v3 incident, v3 outgoing, fl
   const float half_over_pi = 0.5f * ONE_OVER_PI;
   v3 reflected = V(-incident.x, incident.y, -incident.z);
   float ca = vdot(outgoing, reflected); ca = ca < 0.0f ? 0.0f : (ca > 1.0f ? 1.0f : ca);
-  float cap = powf(ca, m->power);
+  float cap = mi_powf(ca, m->power);
   float sd = (m->power + 1.0f) * half_over_pi * cap;
   v3 specular = vscale(vscale(vscale(ld3(m->specular), m->power + 2.0f), half_over_pi), cap);
   bq_t q;
@@ -676,7 +741,7 @@ static v3 sample_phong(rng_t* g, v3 omega, float power) {
   m.c[1] = V(-omega.x, omega.y, -omega.z);
   m.c[2] = vnormalize(vsub(V(0.0f, 1.0f, 0.0f), vscale(m.c[1], m.c[1].y)));
   m.c[0] = vnormalize(vcross(m.c[1], m.c[2]));
-  float y = powf(rng_f(g), 1.0f / (power + 1.0f));
+  float y = mi_powf(rng_f(g), 1.0f / (power + 1.0f));
   float r = sqrtf(1.0f - y * y);
   float sn, cs; sincos_2pi(rng_f(g), &sn, &cs);
   return m3mulv(m, V(r * cs, y, r * sn));
@@ -778,7 +843,7 @@ static edge_t make_edge(const surf_t* fst, const surf_t* snd, v3 omega) {
 }
 /* pow(x, beta) of the MIS weights (PT.cpp:72-74,113-115).  pow(x,1) == x and pow(x,2) == x*x
  * hold exactly for a correctly rounded pow; spelled out so CPU and device agree. */
-static inline float powb(float x, float beta) { return beta == 1.0f ? x : (beta == 2.0f ? x * x : powf(x, beta)); }
+static inline float powb(float x, float beta) { return beta == 1.0f ? x : (beta == 2.0f ? x * x : mi_powf(x, beta)); }
 
 /* ------------------------------------------------------------------ PT */
 typedef struct { surf_t surface; v3 omega, throughput; float density; int finite; } eye_t;

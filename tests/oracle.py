@@ -215,3 +215,13 @@ def rms_abs_errors(rgbn, ref):
     r, a = C.c_float(), C.c_float()
     lib().orc_rms_abs_errors(_ptr(rgbn), _ptr(ref), w, h, C.byref(r), C.byref(a))
     return r.value, a.value
+
+
+def powf(x, y):
+    """The build's own pow(x, y) as the oracle defines it (mi_powf in oracle/pt_oracle.c)."""
+    import ctypes as C
+    x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32); out = np.empty_like(x)
+    L = lib()
+    L.orc_powf.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_powf(x.size, x.ctypes.data, y.ctypes.data, out.ctypes.data)
+    return out

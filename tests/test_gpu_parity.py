@@ -3,8 +3,8 @@ against the CPU oracle on the same seeded inputs.
 
 Bars: bit-exact for integer / index work (LBVH, primitive ids, ray counts, sample counts) and —
 because oracle and device state the same arithmetic contract — bit-exact for the FP32 results of
-the diffuse / mirror / dielectric paths too.  Where a library pow() is involved (Phong, beta not
-in {1, 2}) the tolerance is written in the test.  Full-size runs use size-independent properties
+the diffuse / mirror / dielectric paths too, and for Phong lobes and any beta as well: pow() is the
+build's own definition (mi_powf: FP64 log2 / exp2 polynomials of explicit fmas), stated identically on both sides.  Full-size runs use size-independent properties
 (sample counts, additivity over sample ranges, determinism, furnace value)."""
 import os
 
@@ -130,11 +130,8 @@ def test_per_path_radiance_bit_exact(name, max_path):
     xy, si = grid_paths(48, 40, 6)
     gr, gc = pt.trace_paths(48, 40, xy, si, seed=7); orr, oc = orc.trace_paths(48, 40, xy, si, seed=7)
     assert np.array_equal(gc, oc)
-    if name in ("DoubleLight",):  # Phong materials: library powf differs in the last bits between libm and the device
-        np.testing.assert_allclose(gr, orr, rtol=2e-5, atol=1e-7)
-    else:
-        same = (gr.view(np.uint32) == orr.view(np.uint32)) | (np.isnan(gr) & np.isnan(orr))
-        assert same.all(), "mismatching paths: %s" % np.nonzero(~same.all(1))[0][:10]
+    same = (gr.view(np.uint32) == orr.view(np.uint32)) | (np.isnan(gr) & np.isnan(orr))  # DoubleLight has Phong materials: own pow on both sides
+    assert same.all(), "mismatching paths: %s" % np.nonzero(~same.all(1))[0][:10]
 
 
 @pytest.mark.parametrize("beta,roulette,lights", [(2.0, 0.5, 1.0), (1.0, 1.0, 0.0), (1.5, 0.9, 1.0), (0.0, 0.3, 2.0)])
@@ -144,10 +141,7 @@ def test_parameters_follow_the_reference_semantics(cornell, beta, roulette, ligh
     xy, si = grid_paths(32, 32, 4)
     gr, gc = pt.trace_paths(32, 32, xy, si, seed=3); orr, oc = orc.trace_paths(32, 32, xy, si, seed=3)
     assert np.array_equal(gc, oc)
-    if beta in (1.0, 2.0):
-        assert np.array_equal(gr, orr)
-    else:  # pow(x, beta) through the math libraries: tolerance 2e-5 relative
-        np.testing.assert_allclose(gr, orr, rtol=2e-5, atol=1e-7)
+    assert np.array_equal(gr, orr)  # beta = 1.5 goes through mi_powf on both sides
 
 
 @pytest.mark.parametrize("kernel", [ma.KERNEL_MEGA_LDS, ma.KERNEL_MEGA_GLOBAL, ma.KERNEL_WAVEFRONT])
@@ -284,15 +278,12 @@ def test_full_size_stand_ins_properties(label, spec, w, h, spp):
     a = pt.render_rgbn(w, h, spp=2, seed=3, window=win); r = oracle.Oracle(s).render_rgbn(w, h, spp=2, seed=3, window=win)
     x0, y0, ww, hh = win
     assert np.array_equal(a[..., 3], r[..., 3])
-    if any(m.type == ma.BSDF_PHONG for m in s.materials):  # library powf: per-pixel tolerance instead of 1 ulp
-        assert np.isclose(a[y0:y0 + hh, x0:x0 + ww], r[y0:y0 + hh, x0:x0 + ww], rtol=1e-3, atol=1e-5).mean() > 0.99
-    else:
-        np.testing.assert_allclose(a, r, rtol=1.2e-7, atol=0)
+    np.testing.assert_allclose(a, r, rtol=1.2e-7, atol=0)  # Phong scenes too: one FP32 rounding of the same FP64 sums
 
 
 def test_large_procedural_scene_deep_tree():
     """C4' stand-in at test size (~60k triangles, BVH depth > 24, HBM-resident scene, Phong + mirror + glass):
-    LBVH bit-exact, closest hit / shadow rays bit-exact, per-path radiance within the Phong (powf) tolerance."""
+    LBVH bit-exact, closest hit / shadow rays bit-exact, per-path radiance and ray counts bit-exact."""
     s = sb.atrium(60000)
     pt, orc = ma.PathTracing(s), oracle.Oracle(s)
     assert pt.get_kernel() == ma.KERNEL_MEGA_GLOBAL
@@ -308,10 +299,9 @@ def test_large_procedural_scene_deep_tree():
     rng = np.random.default_rng(1); n = 8000
     xy = np.stack([rng.integers(0, 320, n), rng.integers(0, 180, n)], 1).astype(np.uint32); si = rng.integers(0, 64, n).astype(np.uint64)
     g, gc = pt.trace_paths(320, 180, xy, si, seed=2); r, rc = orc.trace_paths(320, 180, xy, si, seed=2)
-    same_flow = (gc == rc).all(1)
-    assert same_flow.mean() > 0.99  # a 1-ulp powf difference can flip a roulette / side / visibility test: rare divergent paths
-    close = np.isclose(g, r, rtol=5e-5, atol=1e-6, equal_nan=True).all(1)
-    assert close.mean() > 0.995, close.mean()
+    assert np.array_equal(gc, rc)
+    same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
+    assert same.all(), "mismatching paths: %s" % np.nonzero(~same.all(1))[0][:10]
     # image level (BASELINE.md rule): RMSE(GPU, CPU) <= 1.5 x RMSE(CPU, CPU') at equal spp
     a = orc.render_rgbn(96, 54, spp=8, seed=1)[..., :3] / 8; b = orc.render_rgbn(96, 54, spp=8, seed=2)[..., :3] / 8
     gimg = pt.render_rgbn(96, 54, spp=8, seed=1)[..., :3] / 8
@@ -319,18 +309,17 @@ def test_large_procedural_scene_deep_tree():
     assert rmse(gimg, a) <= 1.5 * rmse(a, b)
 
 
-def test_phong_scene_within_stated_tolerance():
-    """CornellBoxPhong: every wall is a PhongBSDF (library powf on both sides): tolerance 5e-5 relative per path."""
+def test_phong_scene_is_bit_exact():
+    """CornellBoxPhong: every wall is a PhongBSDF; cos^n and the lobe sampling go through mi_powf on both sides."""
     s = load_scene("CornellBoxPhong")
     pt, orc = ma.PathTracing(s, max_path=6), oracle.Oracle(s, max_path=6)
     xy, si = grid_paths(40, 40, 4)
     g, gc = pt.trace_paths(40, 40, xy, si, seed=5); r, rc = orc.trace_paths(40, 40, xy, si, seed=5)
-    same_flow = (gc == rc).all(1)
-    assert same_flow.mean() > 0.995
-    close = np.isclose(g, r, rtol=5e-5, atol=1e-6, equal_nan=True).all(1)
-    assert close.mean() > 0.995, close.mean()
-    img = pt.render_rgbn(64, 64, spp=64, seed=1)[..., :3] / 64; ref = orc.render_rgbn(64, 64, spp=64, seed=1)[..., :3] / 64
-    assert abs(img.mean() - ref.mean()) / ref.mean() < 2e-3
+    assert np.array_equal(gc, rc)
+    same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
+    assert same.all(), "mismatching paths: %s" % np.nonzero(~same.all(1))[0][:10]
+    img = pt.render_rgbn(64, 64, spp=64, seed=1); ref = orc.render_rgbn(64, 64, spp=64, seed=1)
+    np.testing.assert_allclose(img, ref, rtol=1.2e-7, atol=0)
 
 
 @pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxSpecular", "TestCaseFurnace", "MirrorBalls", "TestCase27", "MetalRings", "single"])
@@ -368,7 +357,7 @@ def _corpus():
 @pytest.mark.parametrize("name", _corpus())
 def test_reference_corpus_parity(name):
     """Tree, ray counts and per-path radiance against the oracle on every model of the reference that fits a fixture.
-    Bit-exact where no library pow() is involved; Phong scenes (material type 2) within the stated 5e-5."""
+    Bit-exact on all of them, Phong scenes (material type 2) included."""
     s = load_scene(name)
     pt, orc = ma.PathTracing(s), oracle.Oracle(s)
     gn, gs, gm = pt.bvh(); on, os_, om = orc.bvh()
@@ -376,13 +365,9 @@ def test_reference_corpus_parity(name):
     rng = np.random.default_rng(17); n = 6000
     xy = np.stack([rng.integers(0, 96, n), rng.integers(0, 54, n)], 1).astype(np.uint32); si = rng.integers(0, 32, n).astype(np.uint64)
     g, gc = pt.trace_paths(96, 54, xy, si, seed=11); r, rc = orc.trace_paths(96, 54, xy, si, seed=11)
-    if any(m.type == ma.BSDF_PHONG for m in s.materials):
-        assert (gc == rc).all(1).mean() > 0.995
-        assert np.isclose(g, r, rtol=5e-5, atol=1e-6, equal_nan=True).all(1).mean() > 0.995
-    else:
-        assert np.array_equal(gc, rc)
-        same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
-        assert same.all(), "mismatching paths: %s" % np.nonzero(~same.all(1))[0][:10]
+    assert np.array_equal(gc, rc)
+    same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
+    assert same.all(), "mismatching paths: %s" % np.nonzero(~same.all(1))[0][:10]
 
 
 def test_4k_frame_and_window_against_oracle(cornell):

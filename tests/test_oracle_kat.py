@@ -275,3 +275,36 @@ def test_oracle_runs_the_whole_reference_corpus():
         assert np.isfinite(rad).all() and (cnt[:, 0] >= 1).all(), n
         if all(l.diffuse == 0 for l in s.lights):
             assert cnt[:, 1].sum() == 0, n
+
+
+def test_own_powf_is_within_one_ulp_and_follows_c99_special_cases():
+    """mi_powf (Phong lobe, variable beta) is the build's own definition so that device and oracle agree bit for bit; against the
+    exact power it is correctly rounded except for rare last-bit ties, i.e. it is the reference's std::pow for every purpose here."""
+    rng = np.random.default_rng(1)
+    n = 400000
+    x = rng.random(n, dtype=np.float32)
+    y = rng.choice(np.array([1, 2, 3, 5, 10, 50, 100, 500, 1000, 5000, 0.5, 0.25, 1 / 51.0, 1 / 501.0, 1.5, 2.5, 0.7], np.float32), n)
+    tiny = np.finfo(np.float32).tiny
+
+    def exact(a, b):
+        with np.errstate(all="ignore"):
+            r = np.power(a.astype(np.float64), b.astype(np.float64)).astype(np.float32)
+        return np.where(np.abs(r) < tiny, np.float32(0) * r, r)   # FTZ like main.cpp:70-71
+
+    def ulps(a, b):
+        return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+    u = ulps(oracle.powf(x, y), exact(x, y))
+    assert u.max() <= 1 and (u > 0).mean() < 1e-4
+    x = np.exp(rng.uniform(-40, 40, n)).astype(np.float32); y = rng.uniform(-20, 20, n).astype(np.float32)
+    o, r = oracle.powf(x, y), exact(x, y)
+    fin = np.isfinite(o) & np.isfinite(r)
+    assert np.array_equal(np.isinf(o), np.isinf(r)) and ulps(o[fin], r[fin]).max() <= 1
+    inf, nan = np.inf, np.nan
+    xs = np.array([0, 0, 1, -1, -1, -2, -2, -2, inf, inf, 0.5, 2, 0.5, 2, nan, 3, -8, 1e-30, 1e30, -1, 7], np.float32)
+    ys = np.array([2, -2, nan, 3, 2, 3, 2, 0.5, 2, -2, inf, inf, -inf, -inf, 0, nan, 1 / 3.0, 5, 5, inf, 0], np.float32)
+    o, r = oracle.powf(xs, ys), exact(xs, ys)
+    assert ((o == r) | (np.isnan(o) & np.isnan(r))).all(), (o, r)
+    # frozen values: a change of the definition must show up here, not only as a device mismatch
+    kx = np.array([0.5, 0.9, 0.999, 0.25, 0.75, 1e-3], np.float32); ky = np.array([50, 500, 5000, 1 / 51.0, 1.5, 0.7], np.float32)
+    assert oracle.powf(kx, ky).view(np.uint32).tolist() == exact(kx, ky).view(np.uint32).tolist()

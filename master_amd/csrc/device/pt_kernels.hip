@@ -60,7 +60,7 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 #define MI_WAVES_HBM_LARGE 7  // scenes of >= kLargeSceneTris triangles: latency-bound gathers want occupancy (atrium +12 %, clutter +4 % over 5 waves); -11 % on a 2 k-triangle scene
 #endif
 
-template <bool LDS_SCENE, bool LIST, bool COUNT, int WAVES, int QN>
+template <bool LDS_SCENE, bool LIST, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll>
 __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParams p) {
   extern __shared__ float4 smem[];
   const uint32_t tid = threadIdx.x;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
               const Material lm = load_material(sb, sv, sp.material_id);
               f3 le; float dens;
               query_lsdf(sb, sv, lm.light_id, omega, le, dens);
-              float wInv = powb(dens, p.beta) / powb(fG * bs_density, p.beta) + 1.0f;
+              float wInv = powb<FEAT>(dens, p.beta) / powb<FEAT>(fG * bs_density, p.beta) + 1.0f;
               if (!bs_finite) wInv = 1.0f;
               radiance = radiance + (le * ztp) / wInv;
               org = nudge(sp.position, sp.gnormal, dir);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         // ---- vertex x = sp: NEE (PT.cpp:41) then BSDF sample (PT.cpp:43-44) ----
         const Material mat = load_material(sb, sv, sp.material_id);
         const f3 x_omega = -dir;
-        nee = connect_prepare(sb, sv, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
+        nee = connect_prepare<FEAT>(sb, sv, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
         if (pending) { t_shadow = true; ++path_shadow; }
         MI_STAMP(3);  // NEE set-up
         // a contribution that is exactly zero (delta BSDF at x, black surface) cannot change the sum whatever the
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         }
         MI_STAMP(4);  // shadow traversal
         const f3 x_position = sp.position, x_gnormal = sp.gnormal;
-        const BSample bs = bsdf_sample(mat, rng, sp, x_omega);
+        const BSample bs = bsdf_sample<FEAT>(mat, rng, sp, x_omega);
         const float bCos = fabsf(dot(-bs.omega, sp.tangent.c1));  // Edge::bCosTheta with omega = -bsdf.omega
         tnum = (x_throughput * bs.q.throughput) * bCos;
         bs_density = bs.q.density; bs_finite = bs.q.finite != 0;
@@ -444,9 +444,17 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, b
     else fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM, 0> : pt_megakernel<false, false, false, MI_WAVES_HBM, 0>;
   } else
   if (count) fn = lds_scene ? pt_megakernel<true, false, true, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, false, true, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, false, true, MI_WAVES_HBM, 1>);
-  else if (lds_scene) fn = list ? pt_megakernel<true, true, false, MI_WAVES_LDS, 0> : pt_megakernel<true, false, false, MI_WAVES_LDS, 0>;
-  else if (large) fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, false, false, MI_WAVES_HBM_LARGE, 2>;
-  else fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM, 1> : pt_megakernel<false, false, false, MI_WAVES_HBM, 1>;
+  else if (list) fn = lds_scene ? pt_megakernel<true, true, false, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, true, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, true, false, MI_WAVES_HBM, 1>);
+  else {
+    // the compiled feature set that covers the scene: any combination of Phong lobes and mirrors / glass with beta in {1, 2}, or everything
+#define MI_PICK(L, W, Q) (feat == 0 ? pt_megakernel<L, false, false, W, Q, 0> : feat == 1 ? pt_megakernel<L, false, false, W, Q, 1> : \
+                          feat == 2 ? pt_megakernel<L, false, false, W, Q, 2> : feat == 3 ? pt_megakernel<L, false, false, W, Q, 3> : pt_megakernel<L, false, false, W, Q>)
+    const int feat = p.features <= 3u ? int(p.features) : kFeatAll;
+    if (lds_scene) fn = MI_PICK(true, MI_WAVES_LDS, 0);
+    else if (large) fn = MI_PICK(false, MI_WAVES_HBM_LARGE, 2);
+    else fn = MI_PICK(false, MI_WAVES_HBM, 1);
+#undef MI_PICK
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(kBlock), lds, stream, p);

@@ -137,6 +137,15 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   p.max_path = mp >= 0x03FFFFFFull ? 0xFFFFFFFFu : uint32_t(mp);  // the kernel's path_size field has 26 bits: >= 2^26 - 1 edges = unlimited
   p.min_subpath = h->params.min_subpath;
   p.beta = h->params.beta; p.roulette = h->params.roulette; p.lights = h->params.lights;
+  // what the scene needs of the BSDF code (kFeat* in pt_device.h); MI_PT_PLAIN_KERNEL=0 keeps the general variant (A/B)
+  uint32_t f = 0;
+  for (const mi_material& m : h->scene.materials) {
+    if (m.type == MI_BSDF_PHONG) f |= 1u;
+    if (m.type == MI_BSDF_REFLECTION || m.type == MI_BSDF_TRANSMISSION) f |= 2u;
+  }
+  if (p.beta != 1.0f && p.beta != 2.0f) f |= 4u;
+  const char* e = std::getenv("MI_PT_PLAIN_KERNEL");
+  p.features = (e && std::atoi(e) == 0) ? 7u : f;
 }
 
 }  // namespace

@@ -443,6 +443,22 @@ def test_one_process_multi_device_render_is_bit_identical(cornell, kernel):
         ma.render_multi([pts[0], pts[0]], 32, 32)
 
 
+@pytest.mark.parametrize("name,beta", [("CornellBoxDiffuse", 1.0), ("CornellBoxDiffuse", 2.0), ("CornellBoxSpecular", 1.0), ("MirrorBalls", 2.0),
+                                       ("DoubleLight", 1.0), ("CornellBoxDiffuse", 1.5), ("LivingRoomLit", 1.0), ("TestCase27", 1.0)])
+def test_feature_specialised_kernels_render_the_same_image(monkeypatch, name, beta):
+    """Scenes without Phong lobes / mirrors / glass / a general beta run megakernel variants compiled without that code
+    (RenderParams::features); the image is the one the general variant renders, bit for bit, and the oracle's up to the FP32 cast."""
+    s = get_scene(name)
+    pt = ma.PathTracing(s, max_path=7, beta=beta)
+    a = pt.render_rgbn(72, 56, spp=6, seed=4); sa = (pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays)
+    monkeypatch.setenv("MI_PT_PLAIN_KERNEL", "0")
+    b = pt.render_rgbn(72, 56, spp=6, seed=4); sb_ = (pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and sa == sb_
+    orc = oracle.Oracle(s, max_path=7, beta=beta)
+    np.testing.assert_allclose(a, orc.render_rgbn(72, 56, spp=6, seed=4), rtol=1.2e-7, atol=0)
+    assert sa == (orc.last_stats.num_basic_rays, orc.last_stats.num_shadow_rays)
+
+
 def test_degenerate_and_coincident_triangles():
     """Zero-area triangles are never hit (den == 0); coincident triangles tie on t and the smaller global index wins —
     on the device (BVH order) exactly as in the oracle (index order)."""

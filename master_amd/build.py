@@ -18,7 +18,9 @@ SOURCES = [
     "device/pt_kernels.hip",
     "device/bvh_build.hip",
     "device/wf_kernels.hip",
-    "device/bpt_kernels.hip",
+    "device/bpt_kernels.hip",                                                                       # every BSDF, any beta
+    ("device/bpt_kernels.hip", ["-DMI_BPT_FEAT=3", "-DMI_BPT_NS=bpt_fixed"], "bpt_fixed"),          # beta in {0, 1, 2}
+    ("device/bpt_kernels.hip", ["-DMI_BPT_FEAT=0", "-DMI_BPT_NS=bpt_plain"], "bpt_plain"),          # ... and diffuse surfaces only
     "scene_host.cpp",
     "blend_reader.cpp",
     "exr_io.cpp",
@@ -41,7 +43,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s if isinstance(s, str) else s[0]) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -66,9 +68,10 @@ def _build(verbose, extra_flags):
               "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
     objs = []
     procs = []
-    for src in SOURCES:
-        obj = os.path.join(objdir, src.replace("/", "_") + ".o")
-        cmd = [hipcc()] + common
+    for entry in SOURCES:
+        src, variant_flags, tag = entry if isinstance(entry, tuple) else (entry, [], "")
+        obj = os.path.join(objdir, src.replace("/", "_") + ("." + tag if tag else "") + ".o")
+        cmd = [hipcc()] + common + list(variant_flags)
         if src.endswith(".hip"):
             cmd += ["--offload-arch=gfx950", "-munsafe-fp-atomics"]
         else:

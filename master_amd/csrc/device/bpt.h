@@ -29,9 +29,30 @@ struct BptState {
   float* list_splat_sum; uint32_t* list_counts3;  // list mode outputs (mi_bpt_trace_paths)
 };
 
-hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list, hipStream_t stream);
-hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, bool lds_scene, hipStream_t stream, uint32_t* total_items);
-hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, bool lds_scene, uint32_t total_items, hipStream_t stream);
-hipError_t bpt_launch_commit(const RenderParams& p, const BptState& w, hipStream_t stream);
+// launchers of one compiled feature set (bpt_kernels.hip is built once per set)
+#define MI_BPT_DECLARE(ns)                                                                                                                        \
+  namespace ns {                                                                                                                                  \
+  hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list, hipStream_t stream);                                            \
+  hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, bool lds_scene, hipStream_t stream, uint32_t* total_items);      \
+  hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, bool lds_scene, uint32_t total_items, hipStream_t stream);     \
+  hipError_t bpt_launch_commit(const RenderParams& p, const BptState& w, hipStream_t stream);                                                      \
+  }
+MI_BPT_DECLARE(bpt_all)    // every BSDF, any beta
+MI_BPT_DECLARE(bpt_fixed)  // every BSDF, beta in {0, 1, 2}
+MI_BPT_DECLARE(bpt_plain)  // no Phong lobes, no mirrors / glass, beta in {0, 1, 2}
+#undef MI_BPT_DECLARE
+
+struct BptLaunchers {
+  hipError_t (*frame)(const RenderParams&, const BptState&, bool, hipStream_t);
+  hipError_t (*trace)(const RenderParams&, const BptState&, bool, bool, hipStream_t, uint32_t*);
+  hipError_t (*connect)(const RenderParams&, const BptState&, bool, bool, uint32_t, hipStream_t);
+  hipError_t (*commit)(const RenderParams&, const BptState&, hipStream_t);
+};
+// the set compiled for `features` (RenderParams::features, kFeat* bits; for BPT kFeatPow means beta not in {0, 1, 2})
+inline BptLaunchers bpt_launchers(uint32_t features) {
+  if (features == 0u) return {bpt_plain::bpt_launch_frame, bpt_plain::bpt_stage_trace, bpt_plain::bpt_stage_connect, bpt_plain::bpt_launch_commit};
+  if ((features & 4u) == 0u) return {bpt_fixed::bpt_launch_frame, bpt_fixed::bpt_stage_trace, bpt_fixed::bpt_stage_connect, bpt_fixed::bpt_launch_commit};
+  return {bpt_all::bpt_launch_frame, bpt_all::bpt_stage_trace, bpt_all::bpt_stage_connect, bpt_all::bpt_launch_commit};
+}
 
 }  // namespace mi

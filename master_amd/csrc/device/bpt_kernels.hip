@@ -14,7 +14,16 @@
 #include "pt_device.h"
 #include "bpt.h"
 
+// This file is compiled three times (master_amd/build.py): with every BSDF (bpt_all), without pow(x, beta) for the reference's
+// FixedBeta<0|1|2> techniques (bpt_fixed), and additionally without Phong lobes, mirrors and glass (bpt_plain).  The host picks
+// the set that covers the scene and beta; kernels that do not contain the unused code spill less (Cornell box: 55.3 -> 49.6 ms).
+#ifndef MI_BPT_FEAT
+#define MI_BPT_FEAT 7  // kFeat* bits (pt_device.h)
+#define MI_BPT_NS bpt_all
+#endif
+
 namespace mi {
+namespace MI_BPT_NS {
 
 namespace {
 
@@ -33,7 +42,7 @@ MI_DEV float betaf(const Ctx& c, float x) {  // Beta.hpp:24-41
   if (c.beta == 0.0f) return x == 0.0f ? 0.0f : 1.0f;
   if (c.beta == 1.0f) return x;
   if (c.beta == 2.0f) return x * x;
-  return mi_powf(x, c.beta);
+  return (MI_BPT_FEAT & kFeatPow) ? mi_powf(x, c.beta) : x * x;
 }
 
 // ---- Sample.inl:5-37 angular_bound, :121-133 lambert_adjust ----
@@ -93,7 +102,7 @@ MI_DEV BQuery bpt_bsdf_query(const Ctx& c, const Surf& sf, f3 incident, f3 outgo
     q.throughput = F3(v, v, v); q.density = 0.0f; q.densityRev = 1.0f;
     return q;
   }
-  return bsdf_query(m, sf, incident, outgoing);
+  return bsdf_query<MI_BPT_FEAT>(m, sf, incident, outgoing);
 }
 MI_DEV BSample bpt_bsdf_sample(const Ctx& c, Rng& g, const Surf& sf, f3 omega) {
   const Material m = load_material(c.sb, *c.sv, sf.material_id);
@@ -121,7 +130,7 @@ MI_DEV BSample bpt_bsdf_sample(const Ctx& c, Rng& g, const Surf& sf, f3 omega) {
     r.omega = -omega; r.q.throughput = F3(v, v, v); r.q.density = 1.0f; r.q.densityRev = 0.0f; r.q.finite = 1;
     return r;
   }
-  return bsdf_sample(m, g, sf, omega);
+  return bsdf_sample<MI_BPT_FEAT>(m, g, sf, omega);
 }
 
 // Scene::intersect / intersectMesh (Scene.cpp:182-227): closest hit with a geometry mask
@@ -906,4 +915,5 @@ hipError_t bpt_launch_commit(const RenderParams& p, const BptState& w, hipStream
   return hipGetLastError();
 }
 
+}  // namespace MI_BPT_NS
 }  // namespace mi

@@ -696,18 +696,19 @@ bool bpt_staged() {  // MI_BPT_STAGED=0 selects the one-kernel form (kept for A/
 }
 // one launch of `w.lanes` paths: the one-kernel form, or trace -> (item count) -> items -> gather
 int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool list, hipStream_t stream) {
-  if (!bpt_staged()) { HIP_TRY(mi::bpt_launch_frame(p, w, list, stream)); return MI_OK; }
+  const mi::BptLaunchers bl = mi::bpt_launchers(p.features);
+  if (!bpt_staged()) { HIP_TRY(bl.frame(p, w, list, stream)); return MI_OK; }
   const bool lds = use_lds_scene(h);  // small scenes: padded copy of the blob in LDS, binary walk
   auto run = [&](mi::BptState& ws, bool* overflow) -> int {
     uint32_t total = 0;
-    HIP_TRY(mi::bpt_stage_trace(p, ws, list, lds, stream, &total));
+    HIP_TRY(bl.trace(p, ws, list, lds, stream, &total));
     unsigned long long over = 0;
     HIP_TRY(hipMemcpy(&over, h->d_counters + 15, sizeof over, hipMemcpyDeviceToHost));
     if (over) { *overflow = true; HIP_TRY(hipMemsetAsync(h->d_counters + 15, 0, sizeof over, stream)); return MI_OK; }
     int rc = ensure(reinterpret_cast<void**>(&h->bpt_values), &h->bpt_values_bytes, size_t(total ? total : 1) * 16);
     if (rc) return rc;
     ws.values = h->bpt_values;
-    HIP_TRY(mi::bpt_stage_connect(p, ws, list, lds, total, stream));
+    HIP_TRY(bl.connect(p, ws, list, lds, total, stream));
     return MI_OK;
   };
   bool overflow = false;
@@ -735,6 +736,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   int rc = fill_camera(h, camera_id, width, height, p);
   if (rc) return rc;
   fill_pt(h, p);
+  if (p.beta == 0.0f && p.features != 7u) p.features &= ~4u;  // FixedBeta<0> needs no pow either (Beta.hpp:24-41)
   p.stack_entries = (bpt_staged() && use_lds_scene(h)) ? h->info.stack_entries : h->stack_entries_hbm;  // staged kernels stage small scenes into LDS
   mi_camera_frame fr;
   rc = mi_camera_setup(&h->scene.cameras[camera_id], float(width) / float(height), &fr);
@@ -820,7 +822,7 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
       rc = bpt_launch(h, p, w, false, stream);
       if (rc) return rc;
     }
-    HIP_TRY(mi::bpt_launch_commit(p, w, stream));
+    HIP_TRY(mi::bpt_launchers(p.features).commit(p, w, stream));
   }
   HIP_TRY(hipEventRecord(h->ev1, stream));
   HIP_TRY(mi::launch_finalize(h->partial, h->d_rgbn, width, height, win.x0, win.y0, win.w, win.h, 1, stream));

@@ -53,6 +53,7 @@ struct RenderParams {
   uint32_t tiles_x, tiles_y;
   uint32_t shard_rank, shard_world, shard_mtx;  // pixel-tile sharding (mi_pt_set_tile_shard): world > 1 = on, mtx = 32x32 tiles per window row
   uint32_t stack_entries;  // per-lane traversal stack capacity (LDS), >= BVH depth
+  uint32_t stack_in_lds;   // the binary walk never needs more than stack_entries: kernels may drop the private spill path
   uint32_t wide_nodes;     // HBM-resident kernels: 0 = 32-byte quantised binary nodes, 1 = 64-byte quantised wide nodes with the 7-wave
                            // register budget (large scenes), 2 = full-precision 64-byte binary nodes (grid too coarse for the scene)
   uint32_t features;       // kFeat* bits the scene and parameters need (pt_device.h): selects the kernel variant compiled without the rest

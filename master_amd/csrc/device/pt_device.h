@@ -118,7 +118,8 @@ constexpr int kEmptyLink = 0x7FFFFFFF;  // unused child slot of a wide node
 // target is LDS next to the private spill array and falls back to FLAT loads/stores with 64-bit address arithmetic
 // on the pop -> next-node critical path; this way push/pop are ds_write_b32 / ds_read_b32.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-struct TravStack {
+template <bool SPILL>
+struct TravStackT {
   lds_u32* lds;
   uint32_t cap;
   uint32_t spill[kStackSpill];
@@ -129,6 +130,15 @@ struct TravStack {
     return uint32_t(sp) < cap ? lds[sp * kBlock] : spill[(uint32_t(sp) - cap) & (kStackSpill - 1)];
   }
 };
+// the whole stack fits its LDS rows (host: depth - 1 <= 12, RenderParams::stack_in_lds): no bounds test on push / pop, no private array
+template <>
+struct TravStackT<false> {
+  lds_u32* lds;
+  uint32_t cap;
+  MI_DEV void push(int sp, uint32_t v) { lds[sp * kBlock] = v; }
+  MI_DEV uint32_t pop(int sp) const { return lds[sp * kBlock]; }
+};
+typedef TravStackT<true> TravStack;
 
 // BVH2 traversal.  `sb` = scene blob base (LDS or HBM).
 // Visit counters (nodes fetched, triangles tested) feed the roofline's algorithmic-bytes figure; they
@@ -137,8 +147,8 @@ struct Visits { uint32_t nodes, tris; uint32_t* wave_iters; };  // wave_iters: L
 
 // NS = node stride in float4 units: 4 in HBM; the LDS copy pads nodes to 5 (80 B) so that lanes reading the same field of
 // different nodes spread over all 32 banks instead of 2 groups of 4 (64 B = 16 banks: every other node collides).
-template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4>
-MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 org, f3 dir,
+template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, class Stack = TravStack>
+MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 org, f3 dir,
                      uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
   const float4* nodes = sb + sv.off_nodes;
   const float4* tris = sb + sv.off_tris;

@@ -60,7 +60,7 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 #define MI_WAVES_HBM_LARGE 7  // scenes of >= kLargeSceneTris triangles: latency-bound gathers want occupancy (atrium +12 %, clutter +4 % over 5 waves); -11 % on a 2 k-triangle scene
 #endif
 
-template <bool LDS_SCENE, bool LIST, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll>
+template <bool LDS_SCENE, bool LIST, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true>
 __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParams p) {
   extern __shared__ float4 smem[];
   const uint32_t tid = threadIdx.x;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   const uint32_t blob_f4 = LDS_SCENE ? lds_scene_f4(sv) : 0u;
   const float4* sb = sv.blob;
   if (LDS_SCENE) { stage_scene_to_lds(smem, sv, tid); sb = smem; }
-  TravStack stack;
+  TravStackT<SPILL> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + blob_f4) + tid);
   stack.cap = p.stack_entries;
   char* acc_base = reinterpret_cast<char*>(smem + blob_f4) + size_t(p.stack_entries) * kBlock * 4 + size_t(wave) * kAccBytesPerWave;
@@ -447,12 +447,12 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, b
   else if (list) fn = lds_scene ? pt_megakernel<true, true, false, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, true, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, true, false, MI_WAVES_HBM, 1>);
   else {
     // the compiled feature set that covers the scene: any combination of Phong lobes and mirrors / glass with beta in {1, 2}, or everything
-#define MI_PICK(L, W, Q) (feat == 0 ? pt_megakernel<L, false, false, W, Q, 0> : feat == 1 ? pt_megakernel<L, false, false, W, Q, 1> : \
-                          feat == 2 ? pt_megakernel<L, false, false, W, Q, 2> : feat == 3 ? pt_megakernel<L, false, false, W, Q, 3> : pt_megakernel<L, false, false, W, Q>)
+#define MI_PICK(L, W, Q, S) (feat == 0 ? pt_megakernel<L, false, false, W, Q, 0, S> : feat == 1 ? pt_megakernel<L, false, false, W, Q, 1, S> : \
+                             feat == 2 ? pt_megakernel<L, false, false, W, Q, 2, S> : feat == 3 ? pt_megakernel<L, false, false, W, Q, 3, S> : pt_megakernel<L, false, false, W, Q, kFeatAll, S>)
     const int feat = p.features <= 3u ? int(p.features) : kFeatAll;
-    if (lds_scene) fn = MI_PICK(true, MI_WAVES_LDS, 0);
-    else if (large) fn = MI_PICK(false, MI_WAVES_HBM_LARGE, 2);
-    else fn = MI_PICK(false, MI_WAVES_HBM, 1);
+    if (lds_scene) fn = p.stack_in_lds ? MI_PICK(true, MI_WAVES_LDS, 0, false) : MI_PICK(true, MI_WAVES_LDS, 0, true);  // shallow tree: stack without the spill path
+    else if (large) fn = MI_PICK(false, MI_WAVES_HBM_LARGE, 2, true);
+    else fn = MI_PICK(false, MI_WAVES_HBM, 1, true);
 #undef MI_PICK
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

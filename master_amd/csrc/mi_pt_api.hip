@@ -34,6 +34,7 @@ struct mi_pt_handle {
   uint4* qnodes4 = nullptr;
   bool float_nodes = false;        // HBM-resident kernels read the full-precision nodes: the 16-bit grid is too coarse for this scene
   bool wide_nodes = false;         // HBM-resident kernels walk the wide nodes (scenes of >= 100 000 triangles; MI_PT_WIDE_NODES=0/1 overrides)
+  bool stack_fits_lds = false;     // depth - 1 <= info.stack_entries: the binary walk needs no spill entries
   uint32_t stack_entries_hbm = 0;  // LDS rows of the traversal stack for kernels that read the scene from HBM (wide walk)
   mi::SceneView sv{};
   uint32_t* d_sorted_tri = nullptr;
@@ -133,6 +134,7 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   p.sv = h->sv;
   p.wide_nodes = h->float_nodes ? 2u : (h->wide_nodes ? 1u : 0u);
   p.stack_entries = (use_lds_scene(h) && h->kernel_choice != MI_PT_KERNEL_WAVEFRONT) ? h->info.stack_entries : h->stack_entries_hbm;
+  p.stack_in_lds = (h->stack_fits_lds && p.stack_entries == h->info.stack_entries) ? 1u : 0u;
   const uint64_t mp = h->params.max_path;
   p.max_path = mp >= 0x03FFFFFFull ? 0xFFFFFFFFu : uint32_t(mp);  // the kernel's path_size field has 26 bits: >= 2^26 - 1 edges = unlimited
   p.min_subpath = h->params.min_subpath;
@@ -294,6 +296,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     const uint32_t se4 = need4 < 12u ? need4 : 12u;
     if (need4 > se4 + 128u) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack (12 LDS + 128 spill entries)");
     h->info.stack_entries = se;
+    h->stack_fits_lds = need <= se;
     h->stack_entries_hbm = se4;
     h->wide_nodes = nt >= 100000u;
     if (const char* e = std::getenv("MI_PT_WIDE_NODES")) h->wide_nodes = std::atoi(e) != 0;

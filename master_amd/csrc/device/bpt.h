@@ -50,6 +50,7 @@ struct BptLaunchers {
 };
 // the set compiled for `features` (RenderParams::features, kFeat* bits; for BPT kFeatPow means beta not in {0, 1, 2})
 inline BptLaunchers bpt_launchers(uint32_t features) {
+  features &= 7u;  // the BPT kernels are not specialised on the number of lights
   if (features == 0u) return {bpt_plain::bpt_launch_frame, bpt_plain::bpt_stage_trace, bpt_plain::bpt_stage_connect, bpt_plain::bpt_launch_commit};
   if ((features & 4u) == 0u) return {bpt_fixed::bpt_launch_frame, bpt_fixed::bpt_stage_trace, bpt_fixed::bpt_stage_connect, bpt_fixed::bpt_launch_commit};
   return {bpt_all::bpt_launch_frame, bpt_all::bpt_stage_trace, bpt_all::bpt_stage_connect, bpt_all::bpt_launch_commit};

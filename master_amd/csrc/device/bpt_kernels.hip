@@ -18,7 +18,7 @@
 // FixedBeta<0|1|2> techniques (bpt_fixed), and additionally without Phong lobes, mirrors and glass (bpt_plain).  The host picks
 // the set that covers the scene and beta; kernels that do not contain the unused code spill less (Cornell box: 55.3 -> 49.6 ms).
 #ifndef MI_BPT_FEAT
-#define MI_BPT_FEAT 7  // kFeat* bits (pt_device.h)
+#define MI_BPT_FEAT 7  // kFeat* bits (pt_device.h) without kFeatLights: the templates' default (all) is what the light code uses here
 #define MI_BPT_NS bpt_all
 #endif
 
@@ -280,7 +280,7 @@ MI_DEV f3 bpt_connect_light(const Ctx& c, const EVert& eye) {
   if (l1norm(b.throughput) < 1.17549435e-38f) return F3(0, 0, 0);  // FLT_MIN
   const Material lm = load_material(c.sb, *c.sv, eye.surface.material_id);
   f3 le; float dens;
-  query_lsdf(c.sb, *c.sv, lm.light_id, eye.omega, le, dens);
+  query_lsdf(c.sb, *c.sv, nullptr, lm.light_id, eye.omega, le, dens);
   const float Cp = (eye.C * betaf(c, b.density) + eye.c * float(eye.finite)) * betaf(c, dens);
   return (le * eye.throughput) / (Cp + 1.0f);
 }

@@ -13,7 +13,7 @@ namespace mi {
 
 // Scene features a kernel variant is compiled for (RenderParams::features): a scene without Phong lobes, mirrors / glass and with beta in {1, 2}
 // runs the variant that has none of that code (C2: 10 860 -> 11 135 Msamples/s, 172 B/lane less scratch).
-constexpr int kFeatPhong = 1, kFeatDelta = 2, kFeatPow = 4, kFeatAll = 7;
+constexpr int kFeatPhong = 1, kFeatDelta = 2, kFeatPow = 4, kFeatLights = 8, kFeatAll = 15;  // kFeatLights: more (or fewer) than one light
 
 
 constexpr int kBlock = 256;  // threads per workgroup = 4 waves
@@ -424,8 +424,11 @@ MI_DEV BSample bsdf_sample(const Material& m, Rng& g, const Surf& sf, f3 omega) 
 MI_DEV const float4* light_rec(const float4* __restrict__ sb, const SceneView& sv, uint32_t id) { return sb + sv.off_lights + 6 * id; }
 
 // Scene::queryLSDF -> AreaLights::queryLSDF (Scene.cpp:128-131, AreaLights.cpp:142-155)
-MI_DEV void query_lsdf(const float4* __restrict__ sb, const SceneView& sv, uint32_t light_id, f3 omega, f3& radiance, float& density) {
-  const float4* L = light_rec(sb, sv, light_id);
+// `light0`: the first light's record in GLOBAL memory.  A scene with exactly one light (FEAT without kFeatLights) reads it from there: the address is
+// wave-uniform, so the record arrives through scalar loads in SGPRs instead of 6 float4 = 24 VGPRs per lane at the point of highest pressure.
+template <int FEAT = kFeatAll>
+MI_DEV void query_lsdf(const float4* __restrict__ sb, const SceneView& sv, const float4* __restrict__ light0, uint32_t light_id, f3 omega, f3& radiance, float& density) {
+  const float4* L = (FEAT & kFeatLights) ? light_rec(sb, sv, light_id) : light0;
   const float4 l2 = L[2], l4 = L[4], l5 = L[5];
   const float c = dot(omega, xyz(l2));
   radiance = xyz(l4) * (c > 0.0f ? 1.0f : 0.0f);
@@ -444,15 +447,18 @@ MI_DEV float powb(float x, float beta) { return beta == 1.0f ? x : (beta == 2.0f
 struct ShadowRay { f3 org, dir; };
 
 template <int FEAT = kFeatAll>
-MI_DEV f3 connect_prepare(const float4* __restrict__ sb, const SceneView& sv, Rng& g, const Material& mat, const Surf& x,
+MI_DEV f3 connect_prepare(const float4* __restrict__ sb, const SceneView& sv, const float4* __restrict__ light0, Rng& g, const Material& mat, const Surf& x,
                           f3 x_omega, f3 x_throughput, float beta, bool& has_shadow, ShadowRay& ray) {
   const float u = rng_f(g);
-  const float* cdf = reinterpret_cast<const float*>(sb + sv.off_cdf);
-  uint32_t id = sv.n_lights - 1;
-  for (uint32_t i = 0; i + 1 < sv.n_lights; ++i) {
-    if (u < cdf[i + 1]) { id = i; break; }
+  const float4* L = light0;
+  if (FEAT & kFeatLights) {
+    const float* cdf = reinterpret_cast<const float*>(sb + sv.off_cdf);
+    uint32_t id = sv.n_lights - 1;
+    for (uint32_t i = 0; i + 1 < sv.n_lights; ++i) {
+      if (u < cdf[i + 1]) { id = i; break; }
+    }
+    L = light_rec(sb, sv, id);
   }
-  const float4* L = light_rec(sb, sv, id);
   const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4], l5 = L[5];
   const float sx = rng_f(g), sy = rng_f(g);
   const float ux = (sx - 0.5f) * l2.w, uy = (sy - 0.5f) * l3.w;

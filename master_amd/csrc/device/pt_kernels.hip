@@ -72,6 +72,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   constexpr int NS = LDS_SCENE ? 5 : 4, SS = LDS_SCENE ? 9 : 8;
   const uint32_t blob_f4 = LDS_SCENE ? lds_scene_f4(sv) : 0u;
   const float4* sb = sv.blob;
+  const float4* __restrict__ light0 = p.sv.blob + p.sv.off_lights;  // global copy of the first light record (one-light variants read it through scalar loads)
   if (LDS_SCENE) { stage_scene_to_lds(smem, sv, tid); sb = smem; }
   TravStackT<SPILL> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + blob_f4) + tid);
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
           if (is_light && p.max_path > 0u) {  // PT.cpp:23-26: directly visible light, continue through it
             const Material lm = load_material(sb, sv, sp.material_id);
             f3 le; float dens;
-            query_lsdf(sb, sv, lm.light_id, -dir, le, dens);
+            query_lsdf<FEAT>(sb, sv, light0, lm.light_id, -dir, le, dens);
             radiance = radiance + le * p.lights;
             org = nudge(sp.position, sp.gnormal, dir);
           } else if (p.max_path < 2u) {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
             if (is_light) {  // PT.cpp:70-79: MIS-weighted emission, then continue through the light
               const Material lm = load_material(sb, sv, sp.material_id);
               f3 le; float dens;
-              query_lsdf(sb, sv, lm.light_id, omega, le, dens);
+              query_lsdf<FEAT>(sb, sv, light0, lm.light_id, omega, le, dens);
               float wInv = powb<FEAT>(dens, p.beta) / powb<FEAT>(fG * bs_density, p.beta) + 1.0f;
               if (!bs_finite) wInv = 1.0f;
               radiance = radiance + (le * ztp) / wInv;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         // ---- vertex x = sp: NEE (PT.cpp:41) then BSDF sample (PT.cpp:43-44) ----
         const Material mat = load_material(sb, sv, sp.material_id);
         const f3 x_omega = -dir;
-        nee = connect_prepare<FEAT>(sb, sv, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
+        nee = connect_prepare<FEAT>(sb, sv, light0, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
         if (pending) { t_shadow = true; ++path_shadow; }
         MI_STAMP(3);  // NEE set-up
         // a contribution that is exactly zero (delta BSDF at x, black surface) cannot change the sum whatever the
@@ -447,13 +448,16 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, b
   else if (list) fn = lds_scene ? pt_megakernel<true, true, false, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, true, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, true, false, MI_WAVES_HBM, 1>);
   else {
     // the compiled feature set that covers the scene: any combination of Phong lobes and mirrors / glass with beta in {1, 2}, or everything
-#define MI_PICK(L, W, Q, S) (feat == 0 ? pt_megakernel<L, false, false, W, Q, 0, S> : feat == 1 ? pt_megakernel<L, false, false, W, Q, 1, S> : \
-                             feat == 2 ? pt_megakernel<L, false, false, W, Q, 2, S> : feat == 3 ? pt_megakernel<L, false, false, W, Q, 3, S> : pt_megakernel<L, false, false, W, Q, kFeatAll, S>)
-    const int feat = p.features <= 3u ? int(p.features) : kFeatAll;
+#define MI_PICK4(L, W, Q, S, B) (f2 == 0 ? pt_megakernel<L, false, false, W, Q, (B) | 0, S> : f2 == 1 ? pt_megakernel<L, false, false, W, Q, (B) | 1, S> : \
+                                 f2 == 2 ? pt_megakernel<L, false, false, W, Q, (B) | 2, S> : pt_megakernel<L, false, false, W, Q, (B) | 3, S>)
+#define MI_PICK(L, W, Q, S) (feat == kFeatAll ? pt_megakernel<L, false, false, W, Q, kFeatAll, S> : (feat & kFeatLights) ? MI_PICK4(L, W, Q, S, kFeatLights) : MI_PICK4(L, W, Q, S, 0))
+    const int feat = (p.features & uint32_t(kFeatPow)) ? kFeatAll : int(p.features);  // a general beta is rare: only the general variant has pow
+    const int f2 = feat & 3;
     if (lds_scene) fn = p.stack_in_lds ? MI_PICK(true, MI_WAVES_LDS, 0, false) : MI_PICK(true, MI_WAVES_LDS, 0, true);  // shallow tree: stack without the spill path
     else if (large) fn = MI_PICK(false, MI_WAVES_HBM_LARGE, 2, true);
     else fn = MI_PICK(false, MI_WAVES_HBM, 1, true);
 #undef MI_PICK
+#undef MI_PICK4
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;

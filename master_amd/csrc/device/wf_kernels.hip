@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void wf_shade(const RenderParams p, const WfSt
           if (is_light && p.max_path > 0u) {  // PT.cpp:23-26: directly visible light, continue through it
             const Material lm = load_material(sb, sv, sp.material_id);
             f3 le; float dens;
-            query_lsdf(sb, sv, lm.light_id, -dir, le, dens);
+            query_lsdf(sb, sv, nullptr, lm.light_id, -dir, le, dens);
             radiance = radiance + le * p.lights;
             org = nudge(sp.position, sp.gnormal, dir);
           } else if (p.max_path < 2u) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void wf_shade(const RenderParams p, const WfSt
             if (is_light) {  // PT.cpp:70-79: MIS-weighted emission, then continue through the light
               const Material lm = load_material(sb, sv, sp.material_id);
               f3 le; float dens;
-              query_lsdf(sb, sv, lm.light_id, omega, le, dens);
+              query_lsdf(sb, sv, nullptr, lm.light_id, omega, le, dens);
               float wInv = powb(dens, p.beta) / powb(fG * bs_density, p.beta) + 1.0f;
               if (!bs_finite) wInv = 1.0f;
               radiance = radiance + (le * ztp) / wInv;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void wf_shade(const RenderParams p, const WfSt
         const Material mat = load_material(sb, sv, sp.material_id);
         const f3 x_omega = -dir;
         bool pending = false; ShadowRay sray; sray.org = F3(0, 0, 0); sray.dir = F3(0, 0, 1);
-        const f3 nee = connect_prepare(sb, sv, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
+        const f3 nee = connect_prepare(sb, sv, nullptr, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
         if (pending) { t_shadow = true; ++cnt.y; }
         // a contribution that is exactly zero cannot change the sum whatever the visibility: counted, not traversed
         if (pending && !(nee.x != 0.0f || nee.y != 0.0f || nee.z != 0.0f)) pending = false;

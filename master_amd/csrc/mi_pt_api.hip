@@ -146,8 +146,9 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
     if (m.type == MI_BSDF_REFLECTION || m.type == MI_BSDF_TRANSMISSION) f |= 2u;
   }
   if (p.beta != 1.0f && p.beta != 2.0f) f |= 4u;
+  if (h->scene.lights.size() != 1) f |= 8u;
   const char* e = std::getenv("MI_PT_PLAIN_KERNEL");
-  p.features = (e && std::atoi(e) == 0) ? 7u : f;
+  p.features = (e && std::atoi(e) == 0) ? 15u : f;
 }
 
 }  // namespace
@@ -739,7 +740,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   int rc = fill_camera(h, camera_id, width, height, p);
   if (rc) return rc;
   fill_pt(h, p);
-  if (p.beta == 0.0f && p.features != 7u) p.features &= ~4u;  // FixedBeta<0> needs no pow either (Beta.hpp:24-41)
+  if (p.beta == 0.0f && p.features != 15u) p.features &= ~4u;  // FixedBeta<0> needs no pow either (Beta.hpp:24-41)
   p.stack_entries = (bpt_staged() && use_lds_scene(h)) ? h->info.stack_entries : h->stack_entries_hbm;  // staged kernels stage small scenes into LDS
   mi_camera_frame fr;
   rc = mi_camera_setup(&h->scene.cameras[camera_id], float(width) / float(height), &fr);

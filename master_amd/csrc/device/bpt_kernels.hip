@@ -25,13 +25,15 @@
 namespace mi {
 namespace MI_BPT_NS {
 
+
 namespace {
 
 struct LVert { Surf surface; f3 omega, throughput; float a, A; int finite; };  // BPT.hpp:14-20
 struct EVert { Surf surface; f3 omega, throughput; float c, C; int finite; };  // BPT.hpp:22-28
 
 struct Ctx {
-  const float4* sb; const SceneView* sv; TravStack* stack;
+  const float4* sb; const SceneView* sv;
+  void* stack;  // TravStackT<QN != 0>: the LDS-resident kernels (QN == 0) run only on trees whose whole stack fits its LDS rows (host), without the spill path
   float beta, roulette, rinv;
   f3 sphere_c; float sphere_r;
   f3 sky_horizon, sky_zenith;
@@ -138,7 +140,7 @@ template <int QN>
 MI_DEV Surf scene_intersect(Ctx& c, const Surf& from, f3 dir, uint32_t mask) {
   const f3 org = nudge(from.position, from.gnormal, dir);
   Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-  traverse<false, false, QN, QN == 0 ? 5 : 4>(c.sb, *c.sv, *c.stack, org, dir, mask, h);  // QN == 0: padded LDS copy of the scene
+  traverse<false, false, QN, QN == 0 ? 5 : 4>(c.sb, *c.sv, *static_cast<TravStackT<(QN != 0)>*>(c.stack), org, dir, mask, h);  // QN == 0: padded LDS copy of the scene
   ++c.n_basic;
   if (h.id == 0xFFFFFFFFu) { Surf s; s.position = F3(0, 0, 0); s.gnormal = F3(0, 0, 0); s.tangent.c0 = s.tangent.c1 = s.tangent.c2 = F3(0, 0, 0); s.material_id = 0xFFFFFFFFu; return s; }
   return query_surface<QN == 0 ? 9 : 8>(c.sb, *c.sv, org, dir, h);
@@ -146,7 +148,7 @@ MI_DEV Surf scene_intersect(Ctx& c, const Surf& from, f3 dir, uint32_t mask) {
 template <int QN>
 MI_DEV float scene_occluded(Ctx& c, const Surf& origin, const Surf& target) {
   ++c.n_shadow;
-  return occluded<false, QN, QN == 0 ? 5 : 4>(c.sb, *c.sv, *c.stack, origin.position, origin.gnormal, target.position, target.gnormal);
+  return occluded<false, QN, QN == 0 ? 5 : 4>(c.sb, *c.sv, *static_cast<TravStackT<(QN != 0)>*>(c.stack), origin.position, origin.gnormal, target.position, target.gnormal);
 }
 
 // AreaLights::sample (AreaLights.cpp:121-140)
@@ -456,7 +458,7 @@ MI_DEV Lane lane_decode(const RenderParams& p, const BptState& w, uint32_t i) {
   }
   return l;
 }
-MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, TravStack* stack, const float4* sb, const SceneView* sv) {
+MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, void* stack, const float4* sb, const SceneView* sv) {
   c.sb = sb; c.sv = sv; c.stack = stack;
   c.beta = p.beta; c.roulette = p.roulette; c.rinv = 1.0f / p.roulette;
   c.sphere_c = F3(w.sphere[0], w.sphere[1], w.sphere[2]); c.sphere_r = w.sphere[3];
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_TRACE_WAVES) void bpt_trace(const Re
   const float4* sb = sv.blob;
   uint32_t scene_f4 = 0;
   if (QN == 0) { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); sb = smem; __syncthreads(); }
-  TravStack stack;
+  TravStackT<(QN != 0)> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
   stack.cap = p.stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_ITEMS_WAVES) void bpt_items(const Re
   const float4* sb = sv.blob;
   uint32_t scene_f4 = 0;
   if (QN == 0) { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); sb = smem; __syncthreads(); }
-  TravStack stack;
+  TravStackT<(QN != 0)> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
   stack.cap = p.stack_entries;
   const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
@@ -769,7 +771,7 @@ namespace {
 template <bool LIST, int QN>
 __global__ __launch_bounds__(kBlock, MI_BPT_WAVES) void bpt_frame(const RenderParams p, const BptState w) {
   extern __shared__ float4 smem[];
-  TravStack stack;
+  TravStackT<(QN != 0)> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
   stack.cap = p.stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;

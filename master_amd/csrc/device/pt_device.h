@@ -283,8 +283,8 @@ MI_DEV f3 nudge(f3 position, f3 gnormal, f3 dir) {
 }
 
 // Scene::occluded (Scene.cpp:151-180): 1 = visible.
-template <bool COUNT = false, int QUANT = 0, int NS = 4>
-MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, TravStack& stack, f3 opos, f3 ognormal, f3 tpos,
+template <bool COUNT = false, int QUANT = 0, int NS = 4, class Stack = TravStack>
+MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 opos, f3 ognormal, f3 tpos,
                       f3 tgnormal, Visits* vis = nullptr) {
   const f3 direction = tpos - opos;  // Scene.cpp:153 normalises; only signs are used
   const f3 ao = opos + (ognormal * (dot(ognormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;

@@ -702,7 +702,7 @@ bool bpt_staged() {  // MI_BPT_STAGED=0 selects the one-kernel form (kept for A/
 int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool list, hipStream_t stream) {
   const mi::BptLaunchers bl = mi::bpt_launchers(p.features);
   if (!bpt_staged()) { HIP_TRY(bl.frame(p, w, list, stream)); return MI_OK; }
-  const bool lds = use_lds_scene(h);  // small scenes: padded copy of the blob in LDS, binary walk
+  const bool lds = use_lds_scene(h) && h->stack_fits_lds;  // small scenes with shallow trees: padded copy of the blob in LDS, binary walk, stack without a spill path
   auto run = [&](mi::BptState& ws, bool* overflow) -> int {
     uint32_t total = 0;
     HIP_TRY(bl.trace(p, ws, list, lds, stream, &total));
@@ -741,7 +741,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   if (rc) return rc;
   fill_pt(h, p);
   if (p.beta == 0.0f && p.features != 15u) p.features &= ~4u;  // FixedBeta<0> needs no pow either (Beta.hpp:24-41)
-  p.stack_entries = (bpt_staged() && use_lds_scene(h)) ? h->info.stack_entries : h->stack_entries_hbm;  // staged kernels stage small scenes into LDS
+  p.stack_entries = (bpt_staged() && use_lds_scene(h) && h->stack_fits_lds) ? h->info.stack_entries : h->stack_entries_hbm;  // staged kernels stage small scenes into LDS
   mi_camera_frame fr;
   rc = mi_camera_setup(&h->scene.cameras[camera_id], float(width) / float(height), &fr);
   if (rc) return rc;

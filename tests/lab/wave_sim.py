@@ -167,3 +167,71 @@ if __name__ == "__main__":
     for theta in (8, 16, 24, 32, 40, 48):
         c2, t2 = simulate_dynamic(paths, theta)
         print("dynamic theta=%2d: cost/segment %.2f  traversal %.2f  -> speed-up %.2fx" % (theta, c2, t2, c / c2))
+
+
+def simulate_tail(paths, K, min_ready=32, n_waves=40):
+    """Static trip structure, but a traversal loop stops once at most K lanes are still walking (and at least min_ready
+    lanes have a result): the stragglers keep their traversal state, sit out the following phases and continue in the same
+    phase of the next trip.  Per lane the sequence of operations is unchanged (results stay bit-identical)."""
+    it = iter(paths); total = 0.0; segs = 0; trav = 0.0
+
+    def loop(parts):
+        nonlocal total, trav
+        n0 = len(parts)
+        done = [l for l in parts if not l["runs"]]
+        act = [l for l in parts if l["runs"]]
+        while act:
+            if len(act) <= K and len(done) >= min(min_ready, n0 - K) and len(done) > 0:
+                break
+            heads = [l["runs"][0] for l in act]
+            c = max(h[0] for h in heads) * C_NODE + (C_LEAF if any(h[1] for h in heads) else 0.0)
+            total += c; trav += c
+            for l in act:
+                l["runs"].pop(0)
+            done += [l for l in act if not l["runs"]]
+            act = [l for l in act if l["runs"]]
+        return done
+
+    for _ in range(n_waves):
+        pool = []
+        for _ in range(64 * 4):
+            p = next(it, None)
+            if p: pool.append(list(p))
+        lane = [None] * 64
+
+        def start(i):
+            if pool:
+                lane[i] = {"path": pool.pop(), "st": "C"}
+                lane[i]["runs"] = list(lane[i]["path"][0][0])
+            else:
+                lane[i] = None
+        for i in range(64): start(i)
+        while any(l is not None for l in lane):
+            cs = [l for l in lane if l and l["st"] == "C"]
+            if cs:
+                for l in loop(cs): l["st"] = "H"
+            hs = [l for l in lane if l and l["st"] == "H"]
+            if hs:
+                total += C_SHADE
+                for l in hs:
+                    sh = l["path"][0][1]
+                    if sh: l["runs"] = list(sh); l["st"] = "S"
+                    else: l["st"] = "B"
+            ss = [l for l in lane if l and l["st"] == "S"]
+            if ss:
+                for l in loop(ss): l["st"] = "B"
+            bs = [i for i, l in enumerate(lane) if l and l["st"] == "B"]
+            if bs:
+                total += C_SAMPLE + C_REGEN
+                for i in bs:
+                    l = lane[i]; segs += 1
+                    l["path"].pop(0)
+                    if l["path"]: l["runs"] = list(l["path"][0][0]); l["st"] = "C"
+                    else: start(i)
+    return total / segs, trav / segs
+
+
+if __name__ == "__main__" and os.environ.get("WAVE_SIM_TAIL", "1") != "0":
+    for K in (0, 2, 4, 8, 12, 16):
+        c3, t3 = simulate_tail(paths, K)
+        print("tail K=%2d: cost/segment %.2f  traversal %.2f  -> speed-up %.2fx" % (K, c3, t3, c / c3))

@@ -35,5 +35,20 @@ for name in scenes:
         cases += 2; paths += n; bad += (m_pt > 0) + (m_bpt > 0)
         print("%-22s beta %.1f roulette %.2f max_path %-4s PT mismatches %d   BPT mismatches %d" % (
             name, p["beta"], p["roulette"], "inf" if p["max_path"] == ma.PTRDIFF_MAX else p["max_path"], m_pt, m_bpt), flush=True)
+# image mode runs the feature-specialised megakernel variants (the list mode above runs the general one): frames against the oracle
+img_bad = 0
+for name in scenes:
+    s = ma.Scene.load(os.path.join(ROOT, "scenes", name + ".miscene"))
+    for k, p in enumerate(params[:3]):
+        pt = ma.PathTracing(s, **p); orc = oracle.Oracle(s, **p)
+        a = pt.render_rgbn(96, 54, spp=6, seed=31 + k, sample_offset=9); st = pt.last_stats
+        b = orc.render_rgbn(96, 54, spp=6, seed=31 + k, sample_offset=9); so = orc.last_stats
+        same = (np.isclose(a, b, rtol=1.2e-7, atol=0) | (np.isnan(a) & np.isnan(b))).all() and np.array_equal(a[..., 3], b[..., 3])
+        counts = (st.num_basic_rays, st.num_shadow_rays, st.numeric_errors) == (so.num_basic_rays, so.num_shadow_rays, so.numeric_errors)
+        cases += 1
+        if not (same and counts):
+            img_bad += 1; bad += 1
+            print("IMAGE MISMATCH %s params %d: pixels %s counts %s" % (name, k, same, counts), flush=True)
+print("images: %d scenes x 3 parameter sets, %d mismatching frames" % (len(scenes), img_bad))
 print("SUMMARY: %d scenes, %d cases, %d paths, %d cases with mismatches, %.0f s" % (len(scenes), cases, paths, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

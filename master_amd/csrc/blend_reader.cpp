@@ -78,11 +78,13 @@ class BlendFile {
     return parse_dna();
   }
 
-  uint32_t rd32(size_t o) const { uint32_t v; std::memcpy(&v, &buf[o], 4); return v; }
-  uint64_t rd64(size_t o) const { uint64_t v; std::memcpy(&v, &buf[o], 8); return v; }
+  // every read is bounds-checked (a damaged file must end in an error message, not in a fault): out of range reads as 0
+  bool in(size_t o, size_t n) const { return o <= buf.size() && n <= buf.size() - o; }
+  uint32_t rd32(size_t o) const { uint32_t v = 0; if (in(o, 4)) std::memcpy(&v, &buf[o], 4); return v; }
+  uint64_t rd64(size_t o) const { uint64_t v = 0; if (in(o, 8)) std::memcpy(&v, &buf[o], 8); return v; }
   uint64_t rdptr(size_t o) const { return psz == 8 ? rd64(o) : rd32(o); }
-  float rdf(size_t o) const { float v; std::memcpy(&v, &buf[o], 4); return v; }
-  int16_t rd16(size_t o) const { int16_t v; std::memcpy(&v, &buf[o], 2); return v; }
+  float rdf(size_t o) const { float v = 0.0f; if (in(o, 4)) std::memcpy(&v, &buf[o], 4); return v; }
+  int16_t rd16(size_t o) const { int16_t v = 0; if (in(o, 2)) std::memcpy(&v, &buf[o], 2); return v; }
 
   const Field* field(const std::string& sname, const std::string& fname) const {
     auto it = struct_by_name.find(sname);
@@ -112,6 +114,7 @@ class BlendFile {
     size_t o = dna->data, end = dna->data + dna->size;
     auto tag = [&](const char* t) { bool ok = o + 4 <= end && std::memcmp(&buf[o], t, 4) == 0; o += 4; return ok; };
     auto strs = [&](std::vector<std::string>& out) {
+      if (o + 4 > end) { o = end; return; }
       uint32_t n = rd32(o); o += 4;
       for (uint32_t i = 0; i < n && o < end; ++i) {
         const char* s = reinterpret_cast<const char*>(&buf[o]);
@@ -128,25 +131,33 @@ class BlendFile {
     strs(types);
     if (!tag("TLEN")) { error = "bad DNA1 (TLEN)"; return false; }
     std::vector<uint16_t> tlen(types.size());
+    if (o > end || 2 * types.size() > end - o) { error = "bad DNA1 (TLEN)"; return false; }
     std::memcpy(tlen.data(), &buf[o], 2 * types.size());
     o += 2 * types.size(); o = (o + 3) & ~size_t(3);
     if (!tag("STRC")) { error = "bad DNA1 (STRC)"; return false; }
+    if (o + 4 > end) { error = "bad DNA1 (STRC)"; return false; }
     uint32_t ns = rd32(o); o += 4;
     for (uint32_t i = 0; i < ns; ++i) {
+      if (o + 4 > end) { error = "bad DNA1 (STRC)"; return false; }
       uint16_t t = uint16_t(rd16(o)), nf = uint16_t(rd16(o + 2)); o += 4;
+      if (t >= types.size() || o > end || size_t(nf) * 4 > end - o) { error = "bad DNA1 (STRC)"; return false; }
       Struct st; st.name = types[t]; st.size = tlen[t];
       size_t off = 0;
       for (uint16_t k = 0; k < nf; ++k) {
         uint16_t ft = uint16_t(rd16(o)), fn = uint16_t(rd16(o + 2)); o += 4;
+        if (ft >= types.size() || fn >= names.size() || names[fn].empty()) { error = "bad DNA1 (STRC)"; return false; }
         const std::string& full = names[fn];
         Field f; f.type = types[ft]; f.offset = off;
         f.is_ptr = full[0] == '*' || full[0] == '(';
         size_t count = 1;
         std::string bare = full;
-        for (size_t p = bare.find('['); p != std::string::npos; p = bare.find('[', p + 1))
-          count *= size_t(std::atoi(bare.c_str() + p + 1));
+        for (size_t p = bare.find('['); p != std::string::npos; p = bare.find('[', p + 1)) {
+          const int dim = std::atoi(bare.c_str() + p + 1);
+          count *= size_t(dim > 0 && dim < (1 << 20) ? dim : 1);
+          if (count > (size_t(1) << 28)) count = size_t(1) << 28;
+        }
         if (bare.find('[') != std::string::npos) bare = bare.substr(0, bare.find('['));
-        if (bare[0] == '(') bare = bare.substr(2, bare.find(')') - 2);
+        if (!bare.empty() && bare[0] == '(') { const size_t q = bare.find(')'); bare = (bare.size() > 2 && q != std::string::npos && q > 2) ? bare.substr(2, q - 2) : std::string(); }
         while (!bare.empty() && bare[0] == '*') bare = bare.substr(1);
         f.name = bare;
         f.size = (f.is_ptr ? psz : tlen[ft]) * count;
@@ -195,6 +206,7 @@ constexpr int LA_NO_DIFF = 0x800;
 std::string id_name(const BlendFile& bf, size_t base) {
   const Field* f = bf.field("ID", "name");
   if (!f) return "";
+  if (!bf.in(base + f->offset, f->size)) return "";
   const char* s = reinterpret_cast<const char*>(&bf.buf[base + f->offset]);
   std::string n(s, strnlen(s, f->size));
   return n.size() > 2 ? n.substr(2) : n;

@@ -75,10 +75,10 @@ int mi_exr_save_rgbn(const char* path, uint32_t width, uint32_t height, const fl
     const int32_t yy = int32_t(y), sz = int32_t(width * 16);
     std::memcpy(&o[off], &yy, 4); std::memcpy(&o[off + 4], &sz, 4);
     const float* row = rgbn + size_t(height - 1 - y) * width * 4;  // vertical flip
-    float* dst = reinterpret_cast<float*>(&o[off + 8]);
+    uint8_t* dst = &o[off + 8];  // not 4-byte aligned in general: the header length is arbitrary
     const int src_of_channel[4] = {2, 1, 0, 3};  // B, G, R, denom
     for (int c = 0; c < 4; ++c)
-      for (uint32_t x = 0; x < width; ++x) dst[size_t(c) * width + x] = row[size_t(x) * 4 + src_of_channel[c]];
+      for (uint32_t x = 0; x < width; ++x) std::memcpy(dst + (size_t(c) * width + x) * 4, &row[size_t(x) * 4 + src_of_channel[c]], 4);
   }
   // save through a temporary + rename like Options.cpp:1271-1278 does when the output exists
   const std::string tmp = std::string(path) + ".tmp";
@@ -117,8 +117,11 @@ int mi_exr_load_rgbn(const char* path, uint32_t* width, uint32_t* height, float*
     if (size < 0 || o + size_t(size) > d.size()) return mi::fail(MI_ERR_IO, bad + "truncated header.");
     if (name == "channels") {
       size_t p = o;
-      while (p < o + size_t(size) && d[p]) {
-        Chan c; size_t b = p; while (d[p]) ++p; c.name.assign(reinterpret_cast<char*>(&d[b]), p - b); ++p;
+      const size_t attr_end = o + size_t(size);
+      while (p < attr_end && d[p]) {
+        Chan c; size_t b = p; while (p < attr_end && d[p]) ++p;
+        if (p + 1 + 16 > attr_end) return mi::fail(MI_ERR_IO, bad + "truncated channel list.");
+        c.name.assign(reinterpret_cast<char*>(&d[b]), p - b); ++p;
         int32_t t; std::memcpy(&t, &d[p], 4); c.type = t; p += 16;
         chans.push_back(c);
       }
@@ -137,6 +140,7 @@ int mi_exr_load_rgbn(const char* path, uint32_t* width, uint32_t* height, float*
     if (chans[c].type != 1 && chans[c].type != 2 && chans[c].type != 0) return mi::fail(MI_ERR_UNSUPPORTED, bad + "bad channel type.");
     line_size += size_t(w) * (chans[c].type == 1 ? 2 : 4);
   }
+  if (line_size == 0 || size_t(h) > d.size() / line_size) return mi::fail(MI_ERR_IO, bad + "truncated pixel data.");  // also bounds the allocation by the file size
   float* out = static_cast<float*>(std::calloc(size_t(w) * size_t(h) * 4, sizeof(float)));
   if (!out) return mi::fail(MI_ERR_OUT_OF_MEMORY, "out of memory");
   bool has_denom = false;
@@ -145,7 +149,7 @@ int mi_exr_load_rgbn(const char* path, uint32_t* width, uint32_t* height, float*
     uint64_t off;
     if (o + size_t(y) * 8 + 8 > d.size()) { std::free(out); return mi::fail(MI_ERR_IO, bad + "truncated offset table."); }
     std::memcpy(&off, &d[o + size_t(y) * 8], 8);
-    if (off + 8 + line_size > d.size()) { std::free(out); return mi::fail(MI_ERR_IO, bad + "truncated pixel data."); }
+    if (off > d.size() || 8 + line_size > d.size() - off) { std::free(out); return mi::fail(MI_ERR_IO, bad + "truncated pixel data."); }
     int32_t yy; std::memcpy(&yy, &d[off], 4);
     const int64_t row = (h - 1) - (int64_t(yy) - win[1]);  // flip back: EXR line 0 = top
     if (row < 0 || row >= h) { std::free(out); return mi::fail(MI_ERR_IO, bad + "bad scan line."); }

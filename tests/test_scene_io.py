@@ -125,3 +125,30 @@ def test_exr_vertical_flip(tmp_path):
     last = raw[-line_bytes:]
     vals = last[8:].view(np.float32).reshape(4, 3)  # B, G, R, denom
     assert np.all(vals[2] == 7.0) and not vals[0].any()
+
+
+def test_host_parsers_survive_damaged_files(tmp_path):
+    """The .blend / .miscene / EXR readers parse files from outside: under AddressSanitizer + UBSan (CPU build; GPU sanitizers are not
+    available) every fixture and a few hundred truncated / bit-damaged copies must end in success or an error code, never in a fault."""
+    import shutil
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "fuzz")
+    src = [os.path.join(root, "tests", "tools", "fuzz_host_parsers.cpp")] + [os.path.join(root, "master_amd", "csrc", f) for f in ("scene_host.cpp", "blend_reader.cpp", "exr_io.cpp")]
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                    "-I", os.path.join(root, "include")] + src + ["-o", exe], check=True)
+    small = tmp_path / "in"; small.mkdir()
+    for n in ("CornellBoxDiffuse", "TestCase0", "TestCase10", "DoubleLight", "CornellBoxSpecular"):
+        shutil.copy(os.path.join(root, "scenes", n + ".miscene"), small)
+    dirs = [str(small)]
+    ref = "/root/reference/models"
+    if os.path.isdir(ref):  # the reference's own .blend files, where they exist (not on the GPU box)
+        few = tmp_path / "blend"; few.mkdir()
+        for n in ("CornellBoxDiffuse", "TestCase0", "TestCase33", "CornellBoxSpecular"):
+            if os.path.exists(os.path.join(ref, n + ".blend")):
+                os.symlink(os.path.join(ref, n + ".blend"), few / (n + ".blend"))
+        dirs.append(str(few))
+    r = subprocess.run([exe, str(tmp_path), "36", "600"] + dirs, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0 and "rejected" in r.stdout, (r.stdout[-400:], r.stderr[-2000:])

@@ -1,0 +1,62 @@
+// ASan/UBSan harness for the host-side parsers (CPU only; GPU sanitizers are not available): every .blend / .miscene file of the
+// directories given on the command line, an EXR round trip, and byte-level mutations / truncations of each input.  A damaged file
+// must end in an error code, never in a fault.  Built and run by tests/test_scene_io.py::test_host_parsers_survive_damaged_files:
+//   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -I include tests/tools/fuzz_host_parsers.cpp master_amd/csrc/{scene_host,blend_reader,exr_io}.cpp
+//   ./a.out <work dir> <mutations per file> <exr mutations> dir...
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <random>
+#include <dirent.h>
+#include "mi_pt.h"
+static std::vector<unsigned char> slurp(const std::string& p) { std::vector<unsigned char> d; FILE* f = fopen(p.c_str(), "rb"); if (!f) return d; fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); d.resize(n); if (fread(d.data(), 1, n, f) != (size_t)n) d.clear(); fclose(f); return d; }
+static void spit(const std::string& p, const std::vector<unsigned char>& d) { FILE* f = fopen(p.c_str(), "wb"); fwrite(d.data(), 1, d.size(), f); fclose(f); }
+static int try_load(const std::string& p) {
+  mi_scene* s = nullptr; int rc;
+  if (p.size() > 6 && p.substr(p.size() - 6) == ".blend") rc = mi_scene_load_blend(p.c_str(), nullptr, &s); else rc = mi_scene_load(p.c_str(), &s);
+  if (rc == 0) { const mi_scene_desc* d = mi_scene_get_desc(s); volatile unsigned x = d->n_triangles + d->n_vertices; (void)x; mi_scene_free(s); }
+  return rc;
+}
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  const std::string work = argv[1]; const int n_mut = atoi(argv[2]), n_exr = atoi(argv[3]);
+  std::mt19937 rng(7);
+  int ok = 0, bad = 0, mut_ok = 0, mut_bad = 0;
+  for (int a = 4; a < argc; ++a) {
+    DIR* dir = opendir(argv[a]); if (!dir) continue;
+    while (dirent* e = readdir(dir)) {
+      std::string n = e->d_name, p = std::string(argv[a]) + "/" + n;
+      bool blend = n.size() > 6 && n.substr(n.size() - 6) == ".blend", ms = n.size() > 8 && n.substr(n.size() - 8) == ".miscene";
+      if (!blend && !ms) continue;
+      std::vector<unsigned char> d = slurp(p);
+      if (d.size() > (8u << 20)) continue;
+      (try_load(p) == 0 ? ok : bad)++;
+      std::string tmp = work + "/m" + (blend ? ".blend" : ".miscene");
+      for (int k = 0; k < n_mut; ++k) {
+        std::vector<unsigned char> m = d;
+        if (k % 12 < 4) m.resize(m.size() * (k % 12 + 1) / 6);                         // truncations
+        else for (int j = 0; j < 1 + k % 12; ++j) m[rng() % m.size()] = (unsigned char)rng();  // byte flips
+        if (k % 12 >= 8 && m.size() > 8) { size_t o = rng() % (m.size() - 4); unsigned v = (k & 1) ? 0xFFFFFFFFu : 0x7FFFFFF0u; memcpy(&m[o], &v, 4); }
+        spit(tmp, m);
+        (try_load(tmp) == 0 ? mut_ok : mut_bad)++;
+      }
+    }
+    closedir(dir);
+  }
+  // EXR: round trip + mutations
+  { std::vector<float> img(37 * 23 * 4); for (size_t i = 0; i < img.size(); ++i) img[i] = float(i % 97) * 0.25f;
+    const char* k[] = {"technique"}; const char* v[] = {"PT"};
+    if (mi_exr_save_rgbn((work + "/t.exr").c_str(), 37, 23, img.data(), 1, k, v)) { printf("exr save failed\n"); return 1; }
+    std::vector<unsigned char> d = slurp(work + "/t.exr");
+    for (int kk = 0; kk < n_exr; ++kk) {
+      std::vector<unsigned char> m = d;
+      if (kk % 4 == 0) m.resize(rng() % m.size()); else for (int j = 0; j < 1 + kk % 7; ++j) m[rng() % m.size()] = (unsigned char)rng();
+      spit((work + "/m.exr").c_str(), m);
+      uint32_t w, h; float* px = nullptr;
+      if (mi_exr_load_rgbn((work + "/m.exr").c_str(), &w, &h, &px) == 0) { volatile float s = px[0] + px[size_t(w) * h * 4 - 1]; (void)s; mi_free(px); mut_ok++; } else mut_bad++;
+    } }
+  printf("files ok %d rejected %d; mutated accepted %d rejected %d\n", ok, bad, mut_ok, mut_bad);
+  return 0;
+}

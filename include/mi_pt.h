@@ -112,7 +112,8 @@ typedef struct mi_scene_desc {
 
 /* PathTracing ctor arguments (PT.cpp:5-13, make_technique.cpp:132-141, Options.hpp:30-37). */
 typedef struct mi_pt_params {
-  uint64_t max_path;   /* --max-path; UINT64_MAX / PTRDIFF_MAX = unlimited (roulette-terminated) */
+  uint64_t max_path;   /* --max-path; UINT64_MAX / PTRDIFF_MAX = unlimited (roulette-terminated); the device cuts a
+                          path after 2^20 edges so that roulette = 1 in a lossless closed scene cannot hang the GPU */
   float beta;          /* --beta      default 1.0                                              */
   float roulette;      /* --roulette  default 0.9                                              */
   float lights;        /* --no-lights => 0, default 1.0                                        */

@@ -136,7 +136,10 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   p.stack_entries = (use_lds_scene(h) && h->kernel_choice != MI_PT_KERNEL_WAVEFRONT) ? h->info.stack_entries : h->stack_entries_hbm;
   p.stack_in_lds = (h->stack_fits_lds && p.stack_entries == h->info.stack_entries) ? 1u : 0u;
   const uint64_t mp = h->params.max_path;
-  p.max_path = mp >= 0x03FFFFFFull ? 0xFFFFFFFFu : uint32_t(mp);  // the kernel's path_size field has 26 bits: >= 2^26 - 1 edges = unlimited
+  // "Unlimited" (Options.hpp:34, PTRDIFF_MAX) is 2^20 edges on the device: with roulette < 1 a path that long has probability < e^-100, so
+  // nothing changes — but roulette = 1 in a lossless closed scene never terminates in the reference, and a kernel that never ends takes the GPU
+  // with it.  Such a path is cut after 2^20 edges (its radiance so far is kept), which bounds a launch instead of hanging it.
+  p.max_path = mp >= (1ull << 20) ? (1u << 20) : uint32_t(mp);
   p.min_subpath = h->params.min_subpath;
   p.beta = h->params.beta; p.roulette = h->params.roulette; p.lights = h->params.lights;
   // what the scene needs of the BSDF code (kFeat* in pt_device.h); MI_PT_PLAIN_KERNEL=0 keeps the general variant (A/B)

@@ -459,6 +459,26 @@ def test_feature_specialised_kernels_render_the_same_image(monkeypatch, name, be
     assert sa == (orc.last_stats.num_basic_rays, orc.last_stats.num_shadow_rays)
 
 
+def test_lossless_closed_scene_with_roulette_one_terminates():
+    """roulette = 1 with unlimited path length in a closed box of albedo 1 never terminates in the reference; the device cuts a path after
+    2^20 edges (mi_pt_params.max_path), so the launch ends — a kernel that never ends would take the GPU with it."""
+    b = sb.Builder()
+    b.add_camera((0, -0.9, 0), (0, 1, 0))
+    m = b.add_material(sb.material(ma.BSDF_DIFFUSE, diffuse=(1.0, 1.0, 1.0)))
+    q = [((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1)), ((-1, -1, 1), (-1, 1, 1), (1, 1, 1), (1, -1, 1)),
+         ((-1, -1, -1), (-1, -1, 1), (1, -1, 1), (1, -1, -1)), ((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1)),
+         ((-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (-1, -1, 1)), ((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1))]
+    for a, c, d, e in q:
+        b.add_quad(a, c, d, e, m)
+    b.add_light((0, 0, 0.5), (0, 0, -1), (0, 1, 0), (0.1, 0.1), (1, 1, 1))
+    pt = ma.PathTracing(b.build(), roulette=1.0)  # max_path = PTRDIFF_MAX
+    img = pt.render_rgbn(1, 1, spp=1, seed=2)
+    st = pt.last_stats
+    # ~10^6 segments: FP32 rounding of the albedo-1 throughput ends the walk (PT.cpp:62-64) or the cut does; either way the launch is bounded
+    assert st.num_paths == 1 and 10000 < st.num_basic_rays < (1 << 22)
+    assert img[0, 0, 3] in (0.0, 1.0)  # kept if its sum is finite
+
+
 def test_degenerate_and_coincident_triangles():
     """Zero-area triangles are never hit (den == 0); coincident triangles tie on t and the smaller global index wins —
     on the device (BVH order) exactly as in the oracle (index order)."""

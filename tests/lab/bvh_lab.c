@@ -109,9 +109,8 @@ ORC_API void lab_set_split(int max_levels) { g_split_levels_max = max_levels; }
 ORC_API void lab_set_split_big(int factor) { g_split_big = factor; } /* also split boxes whose longest side exceeds factor x the median */
 static int cmp_f(const void* a, const void* b) { float x = *(const float*)a, y = *(const float*)b; return x < y ? -1 : x > y ? 1 : 0; }
 
-ORC_API void lab_build_sah(orc_scene* s) {
+static prim_t* gen_prims(orc_scene* s, int* np_out) {
   int n = (int)s->d.n_triangles;
-  if (n < 2) return;
   prim_t* p = (prim_t*)malloc(sizeof(prim_t) * (size_t)n * 64);
   int np = 0;
   float median = 0.0f;
@@ -147,6 +146,15 @@ ORC_API void lab_build_sah(orc_scene* s) {
     }
   }
   fprintf(stderr, "lab: %d triangles -> %d references\n", n, np);
+  *np_out = np;
+  return p;
+}
+
+ORC_API void lab_build_sah(orc_scene* s) {
+  int n = (int)s->d.n_triangles;
+  if (n < 2) return;
+  int np = 0;
+  prim_t* p = gen_prims(s, &np);
   free(s->nodes); s->n_nodes = (uint32_t)(np - 1); s->nodes = (bnode_t*)calloc(s->n_nodes, sizeof(bnode_t));
   n = np;
   float* tmp = (float*)malloc(sizeof(float) * (size_t)n);
@@ -167,6 +175,75 @@ static float union_area2(const float alo[3], const float ahi[3], const float blo
   for (int a = 0; a < 3; ++a) { lo[a] = fminf(alo[a], blo[a]); hi[a] = fmaxf(ahi[a], bhi[a]); }
   return box_area(lo, hi);
 }
+/* ---- PLOC (radius 16, union-area metric) over the same references: tree quality of the device's builder with pre-split triangles ---- */
+static uint64_t lab_expand21(uint64_t v) {
+  v &= 0x1FFFFF; v = (v | v << 32) & 0x1F00000000FFFFull; v = (v | v << 16) & 0x1F0000FF0000FFull;
+  v = (v | v << 8) & 0x100F00F00F00F00Full; v = (v | v << 4) & 0x10C30C30C30C30C3ull; v = (v | v << 2) & 0x1249249249249249ull; return v;
+}
+typedef struct { uint64_t key; prim_t p; } kprim_t;
+static int cmp_kprim(const void* a, const void* b) { uint64_t x = ((const kprim_t*)a)->key, y = ((const kprim_t*)b)->key; return x < y ? -1 : x > y ? 1 : 0; }
+typedef struct { float lo[3], hi[3]; int32_t link; } clus_t;
+static uint32_t g_renum;
+static int32_t renumber(const bnode_t* src, int32_t node, bnode_t* dst) {
+  if (node < 0) return node;
+  uint32_t me = g_renum++;
+  dst[me] = src[node];
+  int32_t a = renumber(src, src[node].link[0], dst), b = renumber(src, src[node].link[1], dst);
+  dst[me].link[0] = a; dst[me].link[1] = b;
+  if (a >= 0) dst[a].parent = me;
+  if (b >= 0) dst[b].parent = me;
+  return (int32_t)me;
+}
+ORC_API void lab_build_ploc_refs(orc_scene* s) {
+  if (s->d.n_triangles < 2) return;
+  int np = 0;
+  prim_t* p = gen_prims(s, &np);
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = 0; i < np; ++i) for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[i].c[a]); hi[a] = fmaxf(hi[a], p[i].c[a]); }
+  kprim_t* kp = (kprim_t*)malloc(sizeof(kprim_t) * (size_t)np);
+  for (int i = 0; i < np; ++i) {
+    uint64_t q[3];
+    for (int a = 0; a < 3; ++a) { float e = hi[a] - lo[a]; float t = e > 0 ? (p[i].c[a] - lo[a]) / e : 0.0f; q[a] = (uint64_t)fminf(fmaxf(t * 2097152.0f, 0.0f), 2097151.0f); }
+    kp[i].key = lab_expand21(q[0]) << 2 | lab_expand21(q[1]) << 1 | lab_expand21(q[2]); kp[i].p = p[i];
+  }
+  qsort(kp, (size_t)np, sizeof(kprim_t), cmp_kprim);
+  clus_t* c = (clus_t*)malloc(sizeof(clus_t) * (size_t)np); clus_t* c2 = (clus_t*)malloc(sizeof(clus_t) * (size_t)np);
+  for (int i = 0; i < np; ++i) { memcpy(c[i].lo, kp[i].p.lo, 12); memcpy(c[i].hi, kp[i].p.hi, 12); c[i].link = kp[i].p.leaf; }
+  bnode_t* tmp = (bnode_t*)calloc((size_t)np, sizeof(bnode_t)); uint32_t nn = 0;
+  int* nb = (int*)malloc(sizeof(int) * (size_t)np);
+  int n = np;
+  while (n > 1) {
+    for (int i = 0; i < n; ++i) {
+      float best = INFINITY; int bj = -1;
+      for (int j = (i > 16 ? i - 16 : 0); j <= i + 16 && j < n; ++j) {
+        if (j == i) continue;
+        float a = union_area2(c[i].lo, c[i].hi, c[j].lo, c[j].hi);
+        if (a < best) { best = a; bj = j; }
+      }
+      nb[i] = bj;
+    }
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+      int j = nb[i];
+      if (nb[j] == i) {
+        if (i < j) {
+          bnode_t* nd = &tmp[nn];
+          memcpy(nd->lo[0], c[i].lo, 12); memcpy(nd->hi[0], c[i].hi, 12); memcpy(nd->lo[1], c[j].lo, 12); memcpy(nd->hi[1], c[j].hi, 12);
+          nd->link[0] = c[i].link; nd->link[1] = c[j].link;
+          for (int a = 0; a < 3; ++a) { c2[m].lo[a] = fminf(c[i].lo[a], c[j].lo[a]); c2[m].hi[a] = fmaxf(c[i].hi[a], c[j].hi[a]); }
+          c2[m].link = (int32_t)nn++; ++m;
+        }
+      } else c2[m++] = c[i];
+    }
+    clus_t* t = c; c = c2; c2 = t; n = m;
+  }
+  free(s->nodes); s->n_nodes = nn; s->nodes = (bnode_t*)calloc(nn, sizeof(bnode_t));
+  g_renum = 0; renumber(tmp, c[0].link, s->nodes);
+  s->nodes[0].parent = UINT32_MAX;
+  s->max_depth = depth_of(s, 0);
+  free(p); free(kp); free(c); free(c2); free(tmp); free(nb);
+}
+
 static int rotate_node(orc_scene* s, int32_t x) {
   bnode_t* nd = &s->nodes[x];
   int changed = 0;

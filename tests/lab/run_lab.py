@@ -28,7 +28,7 @@ def main():
     from master_amd import scenegen
     oracle.ORACLE_LIB = SO; oracle.build = lambda: SO  # the binding resolves every orc_* symbol from the lab build
     L = oracle.lib()
-    L.lab_rotate.argtypes = [C.c_void_p, C.c_int]; L.lab_build_sah.argtypes = [C.c_void_p]; L.lab_sah.argtypes = [C.c_void_p]
+    L.lab_rotate.argtypes = [C.c_void_p, C.c_int]; L.lab_build_sah.argtypes = [C.c_void_p]; L.lab_build_ploc_refs.argtypes = [C.c_void_p]; L.lab_sah.argtypes = [C.c_void_p]
     L.lab_sah.restype = C.c_double
     specs = sys.argv[1:] or ["CornellBoxDiffuse", "CornellBoxSpecular", "MirrorBalls", "MetalRings", "LivingRoomLit", "atrium:60000"]
     for spec in specs:
@@ -40,10 +40,11 @@ def main():
         for variant in os.environ.get("LAB_VARIANTS", "lbvh,ploc,ploc+rot,lbvh+rot,sah,sah+rot").split(","):
             os.environ["MI_PT_BVH"] = "lbvh" if variant.startswith("lbvh") else "ploc"
             o = oracle.Oracle(s)
-            if variant.startswith("sah"):
-                L.lab_set_split(int(variant[3]) if len(variant) > 3 and variant[3].isdigit() else 0)
+            if variant.startswith("sah") or variant.startswith("plocr"):
+                tail = variant[3:] if variant.startswith("sah") else variant[5:]
+                L.lab_set_split(int(tail[0]) if tail and tail[0].isdigit() else 0)
                 L.lab_set_split_big(int(variant.split("big")[1]) if "big" in variant else 0)
-                L.lab_build_sah(o._h)
+                (L.lab_build_sah if variant.startswith("sah") else L.lab_build_ploc_refs)(o._h)
             rot = L.lab_rotate(o._h, 8) if variant.endswith("+rot") else 0
             cnt = (C.c_uint64 * 4)()
             L.lab_counters(cnt, 1)

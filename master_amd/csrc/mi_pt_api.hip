@@ -168,6 +168,10 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     mi_scene_free(tmp);
     return fail(MI_ERR_INVALID_ARGUMENT, "roulette must be in (0, 1]");
   }
+  if (tmp->data.indices.size() / 3 > (size_t(1) << 27) || tmp->data.materials.size() >= (size_t(1) << 30)) {
+    mi_scene_free(tmp);  // the scene blob is addressed in 32-bit float4 units (15 per triangle) and material ids carry 2 tag bits
+    return fail(MI_ERR_UNSUPPORTED, "scene too large: at most 2^27 triangles and 2^30 materials");
+  }
   if (tmp->data.lights.empty()) {  // AreaLights.cpp:217 runtime_assert(num_lights() != 0)
     mi_scene_free(tmp);
     return fail(MI_ERR_INVALID_ARGUMENT, "scene has no area lights");

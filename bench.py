@@ -107,7 +107,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if args.share_gpu:
+    # one rank per GPU: LOCAL_RANK indexes the visible devices.  If the launcher restricts visibility per rank (one visible device
+    # each), every rank uses its device 0; --share-gpu does the same mapping on purpose for rehearsals on fewer GPUs than ranks.
+    if args.share_gpu or local_rank >= torch.cuda.device_count():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:

@@ -32,11 +32,12 @@ MI_DEV f3 xyz(float4 v) { return F3(v.x, v.y, v.z); }
 // Ray / triangle: Embree 2 single-ray Moeller–Trumbore (rtcIntersect / rtcOccluded at
 // Scene.cpp:175,198), mask test of Scene.cpp:42.  ANY = rtcOccluded (t in (0, h.t]).
 // Closest-hit ties: smaller t, then smaller global triangle id (order independent).
-template <bool ANY>
+// MASKED = false: the ray's mask is 0xFFFFFFFF (every geometry mask is one non-zero bit): no test.
+template <bool ANY, bool MASKED = true>
 MI_DEV bool tri_test(const float4* __restrict__ tris, uint32_t pos, f3 org, f3 dir, uint32_t ray_mask, Hit& h) {
   const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
   const uint32_t mask = __float_as_uint(c.z);
-  if (!(mask & ray_mask)) return false;
+  if (MASKED && !(mask & ray_mask)) return false;
   const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
   const uint32_t id = __float_as_uint(c.y);
   const f3 ng = cross(e2, e1);
@@ -147,14 +148,14 @@ struct Visits { uint32_t nodes, tris; uint32_t* wave_iters; };  // wave_iters: L
 
 // NS = node stride in float4 units: 4 in HBM; the LDS copy pads nodes to 5 (80 B) so that lanes reading the same field of
 // different nodes spread over all 32 banks instead of 2 groups of 4 (64 B = 16 banks: every other node collides).
-template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, class Stack = TravStack>
+template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, bool MASKED = true, class Stack = TravStack>
 MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 org, f3 dir,
                      uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
   const float4* nodes = sb + sv.off_nodes;
   const float4* tris = sb + sv.off_tris;
   if (sv.n_nodes == 0) {
     if (COUNT) ++vis->tris;
-    tri_test<ANY>(tris, 0, org, dir, ray_mask, h);
+    tri_test<ANY, MASKED>(tris, 0, org, dir, ray_mask, h);
     return;
   }
   // QUANT (HBM-resident scenes): boxes are read as 16-bit grid coordinates (32 B per node instead of 64).  The
@@ -196,7 +197,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, Stack& 
         }
       } else {
         if (COUNT) { ++vis->tris; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[1], 1u); }
-        const bool hit = tri_test<ANY>(tris, uint32_t(~node), org, dir, ray_mask, h);
+        const bool hit = tri_test<ANY, MASKED>(tris, uint32_t(~node), org, dir, ray_mask, h);
         if (ANY && hit) return;
       }
       if (sp == 0) return;
@@ -237,7 +238,7 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, Stack& 
       }
     } else {
       if (COUNT) { ++vis->tris; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[1], 1u); }
-      const bool hit = tri_test<ANY>(tris, uint32_t(~node), org, dir, ray_mask, h);
+      const bool hit = tri_test<ANY, MASKED>(tris, uint32_t(~node), org, dir, ray_mask, h);
       if (ANY && hit) return;
     }
     if (sp == 0) return;

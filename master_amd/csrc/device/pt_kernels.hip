@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
       Hit h;
       h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
       const uint32_t steps0 = vis_c.nodes + vis_c.tris;
-      traverse<false, COUNT, QN, NS>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);
+      traverse<false, COUNT, QN, NS, false>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);  // unmasked: PT's closest-hit rays see every geometry
       MI_STAMP(1);  // closest-hit traversal
       ++path_basic;
       if (COUNT && h.id != 0xFFFFFFFFu) ++n_hits;

@@ -16,7 +16,7 @@ namespace mi {
 constexpr int kFeatPhong = 1, kFeatDelta = 2, kFeatPow = 4, kFeatLights = 8, kFeatAll = 15;  // kFeatLights: more (or fewer) than one light
 
 
-constexpr int kBlock = 256;  // threads per workgroup = 4 waves
+
 
 struct Hit { float t, u, v; uint32_t id, pos; };  // id = global triangle index, pos = Morton position
 

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   const uint32_t nb = gridDim.x, b = blockIdx.x;
   const uint32_t q = nb >> 3, rr = nb & 7u, xcd = b & 7u, slot = b >> 3;
   const uint32_t logical_block = xcd * q + (xcd < rr ? xcd : rr) + slot;
-  const uint32_t logical_wave = logical_block * 4u + wave;
+  const uint32_t logical_wave = logical_block * uint32_t(kWavesPerBlock) + wave;
 
   uint32_t pool_next, pool_end, tile_x0 = 0, tile_y0 = 0, chunk = 0;
   uint64_t chunk_sample0 = 0;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
 
 // ---- host-callable launchers (declared in launch.h) ----
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
-  return (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0) + size_t(p.stack_entries) * kBlock * 4 + 4 * kAccBytesPerWave;
+  return (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0) + size_t(p.stack_entries) * kBlock * 4 + kWavesPerBlock * kAccBytesPerWave;
 }
 
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream) {

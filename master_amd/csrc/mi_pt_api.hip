@@ -512,7 +512,7 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
   p.n_chunks = (spp + p.chunk_spp - 1) / p.chunk_spp;
   p.spp = spp; p.seed = seed; p.sample_offset = sample_offset;
   const uint64_t n_waves = n_tiles * p.n_chunks;
-  const uint64_t n_blocks = (n_waves + 3) / 4;
+  const uint64_t n_blocks = (n_waves + mi::kWavesPerBlock - 1) / mi::kWavesPerBlock;
   if (n_blocks > 0x7FFFFFFFull) return fail(MI_ERR_UNSUPPORTED, "render too large for one launch");
 
   rc = ensure(reinterpret_cast<void**>(&h->partial), &h->partial_bytes, size_t(p.n_chunks) * width * height * 32);
@@ -691,7 +691,7 @@ int mi_pt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint3
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), h->stream));
     HIP_TRY(mi::wf_run(p, w, false, h->stream, nullptr));
   } else {
-    const uint32_t per_block = 4u * 64u * 16u;
+    const uint32_t per_block = uint32_t(mi::kWavesPerBlock) * 64u * 16u;
     HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), true, false, (n + per_block - 1) / per_block, h->stream));
   }
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -15,7 +15,7 @@
 
 namespace mi {
 
-constexpr int kBlock = 256;  // threads per workgroup of the path kernels; 128 (more, smaller LDS scene copies) measured -16 % on C2 and +-0 on HBM-resident scenes
+constexpr int kBlock = 256;  // threads per workgroup of the path kernels; measured: 128 -> -16 % on C2, +-0 on HBM-resident scenes; 512 -> -7 % on C2, -4 ... -10 % elsewhere
 constexpr int kWavesPerBlock = kBlock / 64;
 
 

@@ -65,7 +65,7 @@ struct mi_pt_handle {
 
 namespace {
 
-constexpr size_t kLdsSceneLimit = 48 * 1024;  // blob bytes; keeps >= 2 workgroups per CU in the 160 KB LDS
+constexpr size_t kLdsSceneLimit = 48 * 1024;  // LDS bytes per workgroup of the LDS-resident kernels (scene copy + stack + sums): >= 3 workgroups per CU
 
 template <class T> int upload(T** dst, const void* src, size_t bytes) {
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), bytes ? bytes : 16));
@@ -354,7 +354,11 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
       h->sphere[0] = cx; h->sphere[1] = cy; h->sphere[2] = cz; h->sphere[3] = std::sqrt(r2);
     }
   }
-  h->lds_fits = size_t(sv.blob_f4 + sv.n_nodes + sv.n_tris) * 16 <= kLdsSceneLimit;  // the LDS copy pads nodes and shading records by one float4
+  // the LDS copy pads nodes and shading records by one float4; with the traversal stack (1 KB per entry) and the FP64 sums (~8 KB) a workgroup
+  // must stay within 48 KB so that three of them fit a CU: measured on seeded soups (tests/tools/lds_limit.py), the LDS-resident kernel wins up
+  // to ~100 triangles (+17 % at 92), ties at 112 (50 KB per workgroup) and loses 24 % at 142 (two workgroups per CU); TestCase8, 126 triangles: +56 %
+  // with the HBM-resident kernel
+  h->lds_fits = size_t(sv.blob_f4 + sv.n_nodes + sv.n_tris) * 16 + size_t(h->info.stack_entries) * 1024 + 8192 <= kLdsSceneLimit;
   guard.h = nullptr;
   *out = h;
   return MI_OK;

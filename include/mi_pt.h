@@ -28,7 +28,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 #endif
 
-#define MI_PT_ABI_VERSION 1
+#define MI_PT_ABI_VERSION 2 /* 2: + mi_pt_render_async / mi_pt_wait / mi_pt_last_launch (additive) */
 
 /* ---- error codes (reference: C++ exceptions, runtime_assert.cpp:7-11, Scene.cpp:55-57) ---- */
 enum {
@@ -203,6 +203,44 @@ int mi_pt_set_tile_shard(mi_pt_handle* h, uint32_t rank, uint32_t world);
 int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_t camera_id, uint32_t width,
                        uint32_t height, mi_window win, uint32_t spp, uint64_t seed, uint64_t sample_offset,
                        float* rgbn_sum, mi_pt_stats* stats);
+
+/* ------------------------------------------------------------------------------------------
+ * Frames in flight — the reference's cadence.  Application::render calls Technique::render ONCE PER SAMPLE
+ * (Application.cpp:41-79; the batch loop is Framework::runBatch, framework.cpp:426-437) and reads the dvec4 view only
+ * when it saves (Application::_save) or compares with a reference image.  A frame of 512 x 512 is 4 096 waves: called
+ * synchronously (mi_pt_render, spp = 1) the GPU idles while the host copies 16 B per pixel and adds it to the view.
+ *
+ * mi_pt_render_async enqueues the frame (samples [sample_offset, sample_offset + spp) of the window, exactly as
+ * mi_pt_render) and returns at once with a ticket; the result lands in a pinned host buffer owned by the handle.
+ * mi_pt_wait blocks until that frame is complete and hands out its buffer ([height][width][4] floats, row 0 = bottom)
+ * and statistics.  Up to MI_PT_FRAMES_IN_FLIGHT frames may be pending; a buffer stays valid until
+ * MI_PT_FRAMES_IN_FLIGHT further frames have been enqueued.  Frames complete in the order they were enqueued; every
+ * ticket must be waited for before its slot is reused (mi_pt_render_async fails with MI_ERR_INVALID_ARGUMENT otherwise).
+ * The adapter's render(k) = wait(frame k) -> view += dvec4(rgbn) -> enqueue(frame k + MI_PT_FRAMES_IN_FLIGHT): frame
+ * k + 1 renders and crosses PCIe while the host adds frame k, and the view after call k holds exactly frames 0..k,
+ * so `--num-samples`, snapshots and `continue` (Application.cpp:226-229,245) see what they saw before.
+ * Random streams depend only on (seed, pixel, sample index): rendering ahead changes nothing in the image.
+ * ---------------------------------------------------------------------------------------- */
+#define MI_PT_FRAMES_IN_FLIGHT 3
+int mi_pt_render_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win,
+                       uint32_t spp, uint64_t seed, uint64_t sample_offset, uint64_t* ticket);
+int mi_pt_wait(mi_pt_handle* h, uint64_t ticket, const float** rgbn_sum, mi_pt_stats* stats);
+
+/* What the last mi_pt_render / mi_pt_render_device / mi_pt_render_async call launched (for measurement: bench.py
+ * prices the launch's compulsory HBM bytes with it). */
+typedef struct mi_pt_launch_info {
+  uint32_t kernel;          /* MI_PT_KERNEL_* that ran                                                        */
+  uint32_t n_blocks;        /* workgroups of 256 threads                                                      */
+  uint32_t n_chunks;        /* sample chunks per pixel tile (one wave owns a tile x chunk)                    */
+  uint32_t chunk_spp;       /* samples per pixel in a chunk                                                   */
+  uint32_t lds_bytes;       /* dynamic LDS per workgroup                                                      */
+  uint32_t wide_nodes;      /* 0 = 32-byte quantised binary nodes, 1 = 64-byte wide nodes, 2 = 64-byte float nodes */
+  uint32_t features;        /* kFeat* bits of the kernel variant                                              */
+  uint32_t lds_tables;      /* 1: materials, lights and the light CDF were staged into LDS by every workgroup */
+  uint64_t partial_bytes;   /* FP64 partial sums written by the path kernel and read by pt_finalize           */
+  uint64_t scene_bytes;     /* scene blob (+ quantised node copies) resident in HBM                           */
+} mi_pt_launch_info;
+int mi_pt_last_launch(mi_pt_handle* h, mi_pt_launch_info* out);
 
 /* Number of HIP devices visible to the process (0 without a GPU; never fails). */
 int mi_pt_device_count(void);

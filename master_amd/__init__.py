@@ -78,6 +78,15 @@ class PtStats(C.Structure):
                 ("phase_cycles", C.c_uint64 * 8), ("wave_loop_bodies", C.c_uint64 * 4)]
 
 
+class LaunchInfo(C.Structure):
+    _fields_ = [("kernel", C.c_uint32), ("n_blocks", C.c_uint32), ("n_chunks", C.c_uint32), ("chunk_spp", C.c_uint32),
+                ("lds_bytes", C.c_uint32), ("wide_nodes", C.c_uint32), ("features", C.c_uint32), ("lds_tables", C.c_uint32),
+                ("partial_bytes", C.c_uint64), ("scene_bytes", C.c_uint64)]
+
+
+FRAMES_IN_FLIGHT = 3  # MI_PT_FRAMES_IN_FLIGHT
+
+
 class SurfacePoint(C.Structure):
     _fields_ = [("position", C.c_float * 3), ("gnormal", C.c_float * 3), ("tangent", C.c_float * 9), ("material_id", C.c_uint32)]
 
@@ -110,6 +119,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 # every symbol include/mi_pt.h declares; tests/test_abi.py checks the library exports them all
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version",
+    "mi_pt_render_async", "mi_pt_wait", "mi_pt_last_launch",
     "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_tile_shard", "mi_pt_render_multi", "mi_pt_device_count", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
     "mi_bpt_render", "mi_bpt_trace_paths", "mi_bpt_set_sky",
     "mi_pt_bvh_download", "mi_pt_blob_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
@@ -135,6 +145,9 @@ def lib():
     L.mi_pt_destroy.restype = None
     L.mi_pt_render.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, C.POINTER(PtStats)]
     L.mi_pt_render_device.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, vp, C.POINTER(PtStats)]
+    L.mi_pt_render_async.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, C.POINTER(u64)]
+    L.mi_pt_wait.argtypes = [vp, u64, C.POINTER(C.POINTER(f32)), C.POINTER(PtStats)]
+    L.mi_pt_last_launch.argtypes = [vp, C.POINTER(LaunchInfo)]
     L.mi_pt_set_kernel.argtypes = [vp, C.c_int]
     L.mi_pt_set_tile_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.mi_pt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, Window, C.c_uint32, C.c_uint64, C.c_uint64, vp, C.POINTER(PtStats)]
@@ -413,6 +426,45 @@ class PathTracing:
                                          C.c_void_p(stream) if stream else None, C.byref(st) if want_stats else None))
         self.last_stats = st if want_stats else None
         return self.last_stats
+
+    def render_async(self, width, height, spp=1, seed=0, sample_offset=0, camera_id=0, window=None):
+        """mi_pt_render_async: enqueue a frame, returns its ticket (up to FRAMES_IN_FLIGHT may be pending)."""
+        t = C.c_uint64()
+        win = Window(*window) if window else Window(0, 0, 0, 0)
+        _check(lib().mi_pt_render_async(self._h, camera_id, width, height, win, spp, seed, sample_offset, C.byref(t)))
+        self._frame_shape = (height, width, 4)
+        return t.value
+
+    def wait(self, ticket, copy=True):
+        """mi_pt_wait: the frame's [H][W][4] sums (a view of the handle's pinned buffer unless copy) and its statistics."""
+        p, st = C.POINTER(C.c_float)(), PtStats()
+        _check(lib().mi_pt_wait(self._h, ticket, C.byref(p), C.byref(st)))
+        self.last_stats = st
+        a = np.ctypeslib.as_array(p, self._frame_shape)
+        return a.copy() if copy else a
+
+    def last_launch(self):
+        li = LaunchInfo()
+        _check(lib().mi_pt_last_launch(self._h, C.byref(li)))
+        return li
+
+    def render_frames(self, view, n_frames, seed=0, camera_id=0, window=None):
+        """The adapter's frame loop (integration/GpuPathTracing.cpp): `n_frames` calls of Technique::render at spp = 1 with
+        FRAMES_IN_FLIGHT frames pending — frame k + 1 renders while the host adds frame k to the dvec4 view."""
+        h, w = view.shape[:2]
+        st = self._statistics
+        first = st.num_samples
+        tickets = []
+        for k in range(min(FRAMES_IN_FLIGHT, n_frames)):
+            tickets.append(self.render_async(w, h, 1, seed, first + k, camera_id, window))
+        for k in range(n_frames):
+            rgbn = self.wait(tickets[k], copy=False)
+            view += rgbn  # _commit_images (Technique.cpp:222-226)
+            st.num_samples += 1
+            st.num_basic_rays += self.last_stats.num_basic_rays
+            st.num_shadow_rays += self.last_stats.num_shadow_rays
+            if k + FRAMES_IN_FLIGHT < n_frames:
+                tickets.append(self.render_async(w, h, 1, seed, first + k + FRAMES_IN_FLIGHT, camera_id, window))
 
     def render(self, view, seed=0, camera_id=0, reference=None, window=None, spp=1):
         """Technique::render (Technique.cpp:15-77): adds `spp` frames (default 1, as the reference) to

@@ -61,6 +61,17 @@ struct mi_pt_handle {
   double* bpt_light = nullptr; size_t bpt_light_bytes = 0;
   float sphere[4] = {0, 0, 0, 0};
   float sky_horizon[3] = {0, 0, 0}, sky_zenith[3] = {0, 0, 0};
+  // frames in flight (mi_pt_render_async / mi_pt_wait): per slot a device framebuffer, its pinned host copy and the launch's counters
+  struct FrameSlot {
+    float* d_rgbn = nullptr; size_t d_bytes = 0;
+    float* h_rgbn = nullptr; size_t h_bytes = 0;
+    unsigned long long* h_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_counters = nullptr, ev_copied = nullptr;
+    uint64_t ticket = 0; bool pending = false; bool launched = false;
+  } slots[MI_PT_FRAMES_IN_FLIGHT];
+  hipStream_t copy_stream = nullptr;
+  uint64_t next_ticket = 1;
+  mi_pt_launch_info last{};
 };
 
 namespace {
@@ -385,6 +396,14 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->h_stage) hipHostFree(h->h_stage);
   if (h->ev2) hipEventDestroy(h->ev2);
+  for (auto& fs : h->slots) {
+    if (fs.pending && fs.ev_copied) (void)hipEventSynchronize(fs.ev_copied);
+    if (fs.d_rgbn) hipFree(fs.d_rgbn);
+    if (fs.h_rgbn) hipHostFree(fs.h_rgbn);
+    if (fs.h_counters) hipHostFree(fs.h_counters);
+    for (hipEvent_t e : {fs.ev0, fs.ev1, fs.ev2, fs.ev_counters, fs.ev_copied}) if (e) hipEventDestroy(e);
+  }
+  if (h->copy_stream) hipStreamDestroy(h->copy_stream);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -415,13 +434,14 @@ int mi_pt_get_kernel(mi_pt_handle* h) {
 
 namespace {
 // counters and event times of the megakernel launch last recorded on `stream` (waits for it)
-int collect_stats(mi_pt_handle* h, hipStream_t stream, mi_pt_stats* stats) {
+struct EventSet { hipEvent_t ev0, ev1, ev2; };
+int collect_stats(mi_pt_handle* h, hipStream_t stream, mi_pt_stats* stats, const EventSet& ev) {
   unsigned long long c[24];
   HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   float t01 = 0.0f, t02 = 0.0f;
-  HIP_TRY(hipEventElapsedTime(&t01, h->ev0, h->ev1));
-  HIP_TRY(hipEventElapsedTime(&t02, h->ev0, h->ev2));
+  HIP_TRY(hipEventElapsedTime(&t01, ev.ev0, ev.ev1));
+  HIP_TRY(hipEventElapsedTime(&t02, ev.ev0, ev.ev2));
   stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
   stats->trace_ms = t01; stats->gpu_ms = t02;
   stats->nodes_closest = c[4]; stats->tris_closest = c[5]; stats->nodes_shadow = c[6]; stats->tris_shadow = c[7]; stats->num_hits = c[8]; stats->wave_steps_closest = c[9]; stats->wave_steps_shadow = c[10];
@@ -429,14 +449,15 @@ int collect_stats(mi_pt_handle* h, hipStream_t stream, mi_pt_stats* stats) {
   for (int k = 0; k < 4; ++k) stats->wave_loop_bodies[k] = c[11 + k];
   return MI_OK;
 }
-}  // namespace
 
-int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp,
-                        uint64_t seed, uint64_t sample_offset, float* rgbn_sum_device, void* stream_v, mi_pt_stats* stats) {
+// Technique::render for `spp` frames: the launches of one call on `stream`, timed by the events of `ev`
+int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp,
+                uint64_t seed, uint64_t sample_offset, float* rgbn_sum_device, void* stream_v, mi_pt_stats* stats, const EventSet& ev) {
   if (!h || !rgbn_sum_device) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render: null argument");
   if (spp == 0) return fail(MI_ERR_INVALID_ARGUMENT, "spp must be > 0");
   mi::RenderParams p;
   std::memset(&p, 0, sizeof p);
+  std::memset(&h->last, 0, sizeof h->last);
   int rc = fill_camera(h, camera_id, width, height, p);
   if (rc) return rc;
   if (win.w == 0 || win.h == 0) { win.x0 = 0; win.y0 = 0; win.w = width; win.h = height; }
@@ -477,20 +498,21 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
     p.partial = h->partial; p.counters = h->d_counters; p.n_chunks = 1; p.chunk_spp = spp;
     p.spp = spp; p.seed = seed; p.sample_offset = sample_offset;
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipEventRecord(h->ev0, stream));
+    HIP_TRY(hipEventRecord(ev.ev0, stream));
     HIP_TRY(hipMemsetAsync(h->partial, 0, size_t(width) * height * 32, stream));
     h->wf_iterations = 0;
+    h->last.kernel = MI_PT_KERNEL_WAVEFRONT; h->last.n_chunks = 1; h->last.chunk_spp = spp; h->last.partial_bytes = uint64_t(width) * height * 32ull;
     HIP_TRY(mi::wf_run(p, w, h->instrumented, stream, &h->wf_iterations));
-    HIP_TRY(hipEventRecord(h->ev1, stream));
+    HIP_TRY(hipEventRecord(ev.ev1, stream));
     HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, 1, stream));
-    HIP_TRY(hipEventRecord(h->ev2, stream));
+    HIP_TRY(hipEventRecord(ev.ev2, stream));
     if (stats) {
       unsigned long long c[24];
       HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       float t01 = 0.0f, t02 = 0.0f;
-      HIP_TRY(hipEventElapsedTime(&t01, h->ev0, h->ev1));
-      HIP_TRY(hipEventElapsedTime(&t02, h->ev0, h->ev2));
+      HIP_TRY(hipEventElapsedTime(&t01, ev.ev0, ev.ev1));
+      HIP_TRY(hipEventElapsedTime(&t02, ev.ev0, ev.ev2));
       std::memset(stats, 0, sizeof *stats);
       stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
       stats->trace_ms = t01; stats->gpu_ms = t02;
@@ -524,13 +546,96 @@ int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uin
   p.partial = h->partial;
   p.counters = h->d_counters;
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), stream));
-  HIP_TRY(hipEventRecord(h->ev0, stream));
+  HIP_TRY(hipEventRecord(ev.ev0, stream));
   if (sharded) HIP_TRY(hipMemsetAsync(h->partial, 0, size_t(p.n_chunks) * width * height * 32, stream));  // pixels of other ranks' tiles
   HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), false, h->instrumented, uint32_t(n_blocks), stream));
-  HIP_TRY(hipEventRecord(h->ev1, stream));
+  {
+    mi_pt_launch_info& li = h->last;
+    li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
+    li.n_blocks = uint32_t(n_blocks); li.n_chunks = p.n_chunks; li.chunk_spp = p.chunk_spp;
+    li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
+    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u;
+    li.partial_bytes = uint64_t(p.n_chunks) * win.w * win.h * 32ull;
+    li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
+  }
+  HIP_TRY(hipEventRecord(ev.ev1, stream));
   HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
-  HIP_TRY(hipEventRecord(h->ev2, stream));
-  if (stats) return collect_stats(h, stream, stats);
+  HIP_TRY(hipEventRecord(ev.ev2, stream));
+  if (stats) return collect_stats(h, stream, stats, ev);
+  return MI_OK;
+}
+
+}  // namespace
+
+int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp,
+                        uint64_t seed, uint64_t sample_offset, float* rgbn_sum_device, void* stream_v, mi_pt_stats* stats) {
+  if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render: null argument");
+  return render_impl(h, camera_id, width, height, win, spp, seed, sample_offset, rgbn_sum_device, stream_v, stats, EventSet{h->ev0, h->ev1, h->ev2});
+}
+
+int mi_pt_last_launch(mi_pt_handle* h, mi_pt_launch_info* out) {
+  if (!h || !out) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_last_launch: null argument");
+  *out = h->last;
+  return MI_OK;
+}
+
+int mi_pt_render_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint64_t seed,
+                       uint64_t sample_offset, uint64_t* ticket) {
+  if (!h || !ticket) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_async: null argument");
+  if (width == 0 || height == 0 || uint64_t(width) * height > (1ull << 31)) return fail(MI_ERR_INVALID_ARGUMENT, "bad resolution");
+  HIP_TRY(hipSetDevice(h->device));
+  auto& fs = h->slots[h->next_ticket % MI_PT_FRAMES_IN_FLIGHT];
+  if (fs.pending) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_async: " + std::to_string(MI_PT_FRAMES_IN_FLIGHT) + " frames are pending; call mi_pt_wait for ticket " + std::to_string(fs.ticket) + " first");
+  const size_t bytes = size_t(width) * height * 16;
+  if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  if (!fs.ev0) {
+    HIP_TRY(hipEventCreate(&fs.ev0)); HIP_TRY(hipEventCreate(&fs.ev1)); HIP_TRY(hipEventCreate(&fs.ev2));
+    HIP_TRY(hipEventCreateWithFlags(&fs.ev_counters, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&fs.ev_copied, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&fs.h_counters), 32 * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  int rc = ensure(reinterpret_cast<void**>(&fs.d_rgbn), &fs.d_bytes, bytes);
+  if (rc) return rc;
+  if (fs.h_bytes < bytes) {
+    if (fs.h_rgbn) hipHostFree(fs.h_rgbn);
+    fs.h_rgbn = nullptr; fs.h_bytes = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&fs.h_rgbn), bytes, hipHostMallocDefault) != hipSuccess) return fail(MI_ERR_OUT_OF_MEMORY, "pinned host framebuffer");
+    fs.h_bytes = bytes;
+  }
+  // the frame's kernels on the render stream (no host synchronisation), its counters behind them; the framebuffer crosses PCIe on
+  // the copy stream, so the next frame's kernels do not wait for it
+  rc = render_impl(h, camera_id, width, height, win, spp, seed, sample_offset, fs.d_rgbn, h->stream, nullptr, EventSet{fs.ev0, fs.ev1, fs.ev2});
+  if (rc) return rc;
+  fs.launched = h->last.n_blocks != 0 || h->kernel_choice == MI_PT_KERNEL_WAVEFRONT;
+  HIP_TRY(hipMemcpyAsync(fs.h_counters, h->d_counters, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipEventRecord(fs.ev_counters, h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->copy_stream, fs.ev_counters, 0));
+  HIP_TRY(hipMemcpyAsync(fs.h_rgbn, fs.d_rgbn, bytes, hipMemcpyDeviceToHost, h->copy_stream));
+  HIP_TRY(hipEventRecord(fs.ev_copied, h->copy_stream));
+  fs.ticket = h->next_ticket++;
+  fs.pending = true;
+  *ticket = fs.ticket;
+  return MI_OK;
+}
+
+int mi_pt_wait(mi_pt_handle* h, uint64_t ticket, const float** rgbn_sum, mi_pt_stats* stats) {
+  if (!h || !rgbn_sum) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait: null argument");
+  auto& fs = h->slots[ticket % MI_PT_FRAMES_IN_FLIGHT];
+  if (!fs.pending || fs.ticket != ticket) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait: ticket " + std::to_string(ticket) + " is not pending");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventSynchronize(fs.ev_copied));
+  fs.pending = false;
+  *rgbn_sum = fs.h_rgbn;
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    if (fs.launched) {
+      const unsigned long long* c = fs.h_counters;
+      float t01 = 0.0f, t02 = 0.0f;
+      HIP_TRY(hipEventElapsedTime(&t01, fs.ev0, fs.ev1));
+      HIP_TRY(hipEventElapsedTime(&t02, fs.ev0, fs.ev2));
+      stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
+      stats->trace_ms = t01; stats->gpu_ms = t02;
+    }
+  }
   return MI_OK;
 }
 
@@ -600,7 +705,7 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
       if (hipMemcpy(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MI_ERR_NO_DEVICE, "counter copy failed"); continue; }
       one.num_basic_rays = c[0]; one.num_shadow_rays = c[1]; one.numeric_errors = c[2]; one.num_paths = c[3];
     } else {
-      const int r2 = collect_stats(h, h->stream, &one);
+      const int r2 = collect_stats(h, h->stream, &one, EventSet{h->ev0, h->ev1, h->ev2});
       if (r2 != MI_OK) { rc = r2; continue; }
     }
     total.num_basic_rays += one.num_basic_rays; total.num_shadow_rays += one.num_shadow_rays; total.numeric_errors += one.numeric_errors;

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     L = ma.lib()
     for f in header_functions():
         getattr(L, f)
-    assert L.mi_pt_abi_version() == 1
+    assert L.mi_pt_abi_version() == 2  # 2: + mi_pt_render_async / mi_pt_wait / mi_pt_last_launch
 
 
 def test_no_torch_or_cxx_types_cross_the_boundary():
@@ -48,6 +48,9 @@ def test_every_entry_point_cites_the_reference():
 def test_struct_sizes():
     assert C.sizeof(ma.Material) == 48 and C.sizeof(ma.Light) == 80 and C.sizeof(ma.Camera) == 40
     assert C.sizeof(ma.SurfacePoint) == 64 and C.sizeof(ma.BvhNode) == 64 and C.sizeof(ma.PtParams) == 24
+    assert C.sizeof(ma.LaunchInfo) == 48
+    hdr = open(os.path.join(ROOT, "include", "mi_pt.h")).read()
+    assert "#define MI_PT_FRAMES_IN_FLIGHT %d" % ma.FRAMES_IN_FLIGHT in hdr
 
 
 def test_load_failure_message_follows_loader():

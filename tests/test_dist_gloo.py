@@ -70,6 +70,49 @@ def _tile_worker(rank, world, port, spp, steps, out_dir):
     dist.destroy_process_group()
 
 
+C5_W, C5_H = 3840, 2160                 # BASELINE configs[4]
+C5_BAND = (0, 1024, 3840, 64)           # two rows of 32x32 tiles of that frame: 240 tiles, both ranks own 120
+
+
+def _c5_worker(rank, world, port, out_dir):
+    """The C5 shape through the N > 1 code path: clutter scene (BreakfastRoom1 stand-in), 3840x2160 frame, tile ownership over the
+    8 160 tiles of the frame, one all-reduce of the full 126.6 MiB [H][W][4] framebuffer.  To stay within CPU-test time the
+    oracle renders one band of the frame (the rest is zero on every rank, as for tiles a rank does not own)."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from master_amd import dist as madist
+    from master_amd import scenegen
+
+    orc = oracle.Oracle(scenegen.clutter())
+    mine = madist.tile_owner(C5_W, C5_H, world) == rank
+    off, n = madist.tile_sample_range(0, world, 1)
+    full = orc.render_rgbn(C5_W, C5_H, spp=n, seed=5, sample_offset=off, window=C5_BAND, threads=2)
+    fb = torch.from_numpy(np.where(mine[..., None], full, np.float32(0)))
+    assert fb.numel() * 4 == 3840 * 2160 * 16
+    madist.merge_framebuffers(fb)
+    x0, y0, w, h = C5_BAND
+    np.save(os.path.join(out_dir, "c5_%d.npy" % rank), fb.numpy()[y0:y0 + h])
+    np.save(os.path.join(out_dir, "c5_outside_%d.npy" % rank), np.array([float(fb[:y0].abs().sum() + fb[y0 + h:].abs().sum()), float(mine.sum())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_tile_sharding_at_the_c5_shape(tmp_path):
+    world = 2
+    mp.spawn(_c5_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import oracle
+    from master_amd import scenegen
+
+    single = oracle.Oracle(scenegen.clutter()).render_rgbn(C5_W, C5_H, spp=world, seed=5, sample_offset=0, window=C5_BAND, threads=4)
+    x0, y0, w, h = C5_BAND
+    b0, b1 = np.load(tmp_path / "c5_0.npy"), np.load(tmp_path / "c5_1.npy")
+    assert np.array_equal(b0, b1) and np.array_equal(b0, single[y0:y0 + h])  # one owner per pixel: the reduce only adds zeros
+    o0, o1 = np.load(tmp_path / "c5_outside_0.npy"), np.load(tmp_path / "c5_outside_1.npy")
+    assert o0[0] == 0 and o1[0] == 0 and o0[1] + o1[1] == C5_W * C5_H and abs(o0[1] - o1[1]) <= 32 * 32 * 120
+
+
 def test_tile_owners_partition_the_window():
     from master_amd import dist as madist
 

@@ -1,0 +1,128 @@
+"""Round-2 parity cases (run with -m gpu on an MI355X):
+
+* the frame cadence of the reference — Application::render calls Technique::render once per sample (Application.cpp:41-79,
+  framework.cpp:426-437) — through mi_pt_render_async / mi_pt_wait: frames in flight give the same view, bit for bit, as the
+  synchronous loop and as the oracle's frames;
+* BASELINE configs[4] (C5) through its stand-in: the seeded `clutter` room at 3840x2160, pixel-tile shard of world size 8 —
+  properties at full size plus windows inside one rank's tiles against the oracle.
+"""
+import numpy as np
+import pytest
+
+import master_amd as ma
+import oracle
+from master_amd import dist as madist
+from master_amd import scenegen as sb
+from conftest import load_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frames_in_flight_give_the_synchronous_view_bit_for_bit(cornell):
+    """render(k) = wait(frame k) -> view += rgbn -> enqueue(frame k + FRAMES_IN_FLIGHT): the dvec4 view after every call holds
+    exactly frames 0..k (what --num-samples / snapshots / continue see), identical to one mi_pt_render(spp = 1) per frame."""
+    pt_a, pt_s = ma.PathTracing(cornell, max_path=6), ma.PathTracing(cornell, max_path=6)
+    w, h, n = 96, 72, 11
+    view_a, view_s = np.zeros((h, w, 4), np.float64), np.zeros((h, w, 4), np.float64)
+    pt_a.render_frames(view_a, n, seed=9)
+    for _ in range(n):
+        pt_s.render(view_s, seed=9)
+    assert np.array_equal(view_a, view_s) and np.all(view_a[..., 3] == n)
+    sa, ss = pt_a.statistics(), pt_s.statistics()
+    assert (sa.num_samples, sa.num_basic_rays, sa.num_shadow_rays) == (ss.num_samples, ss.num_basic_rays, ss.num_shadow_rays)
+    orc = oracle.Oracle(cornell, max_path=6)
+    ref = np.zeros((h, w, 4), np.float64)
+    for k in range(n):  # the oracle's frames, added one by one like Technique::_commit_images
+        ref += orc.render_rgbn(w, h, spp=1, seed=9, sample_offset=k)
+    np.testing.assert_allclose(view_a, ref, rtol=1.2e-7)
+
+
+def test_async_tickets_slots_and_errors(cornell):
+    pt = ma.PathTracing(cornell, max_path=4)
+    t = [pt.render_async(40, 24, 1, 3, k) for k in range(ma.FRAMES_IN_FLIGHT)]
+    assert t == list(range(t[0], t[0] + ma.FRAMES_IN_FLIGHT))
+    with pytest.raises(ma.MiError) as e:  # every slot is pending
+        pt.render_async(40, 24, 1, 3, 99)
+    assert e.value.code == -1 and "pending" in str(e.value)
+    frames = [pt.wait(k) for k in t]
+    with pytest.raises(ma.MiError):  # already handed out
+        pt.wait(t[0])
+    for k, f in enumerate(frames):
+        assert np.array_equal(f, pt.render_rgbn(40, 24, spp=1, seed=3, sample_offset=k))
+    # a window, several samples per frame, statistics of the frame
+    tk = pt.render_async(64, 48, 5, 3, 7, window=(8, 4, 33, 21))
+    f = pt.wait(tk)
+    st = pt.last_stats
+    ref = pt.render_rgbn(64, 48, spp=5, seed=3, sample_offset=7, window=(8, 4, 33, 21))
+    assert np.array_equal(f, ref) and st.num_paths == 33 * 21 * 5 == pt.last_stats.num_paths
+    assert (st.num_basic_rays, st.num_shadow_rays) == (pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays) and st.gpu_ms > 0
+
+
+def test_last_launch_describes_the_launch(cornell):
+    pt = ma.PathTracing(cornell, max_path=8)
+    pt.render_rgbn(512, 512, spp=64, seed=1)
+    li = pt.last_launch()
+    assert li.kernel == ma.KERNEL_MEGA_LDS and li.n_blocks * 4 >= 64 * 64 * li.n_chunks and li.n_chunks * li.chunk_spp >= 64
+    assert li.partial_bytes == li.n_chunks * 512 * 512 * 32 and li.lds_bytes <= 48 * 1024 and li.scene_bytes > 0
+    big = ma.PathTracing(load_scene("LivingRoomLit"))
+    big.render_rgbn(64, 64, spp=2, seed=1)
+    lb = big.last_launch()
+    assert lb.kernel == ma.KERNEL_MEGA_GLOBAL and lb.scene_bytes > 40000 * 15 * 16
+
+
+# ---- BASELINE configs[4] (C5): BreakfastRoom1 stand-in, 3840x2160, pixel tiles sharded over 8 GPUs ----
+C5_W, C5_H, C5_WORLD = 3840, 2160, 8
+
+
+@pytest.fixture(scope="module")
+def clutter():
+    return sb.clutter()
+
+
+@pytest.mark.parametrize("rank", [0, 5])
+def test_c5_workload_tile_shard_properties_and_windows_against_oracle(clutter, rank):
+    """One rank's share of C5': the 32x32 tiles {t : t mod 8 == rank} of the 3840x2160 frame, all samples of them (a bounded
+    number here), zeros elsewhere.  Properties at full size: denom == spp exactly on the owned tiles and 0 elsewhere, path count
+    = owned pixels x spp, no numeric errors lost, additivity over sample ranges; windows inside owned tiles equal the oracle's
+    render of the same window of the same frame (pixel index, camera ray and stream all depend on the full resolution)."""
+    spp = 4
+    pt = ma.PathTracing(clutter)  # unbounded paths (reference default), Phong + mirror + glass, two area lights
+    pt.set_tile_shard(rank, C5_WORLD)
+    img = pt.render_rgbn(C5_W, C5_H, spp=spp, seed=0x5EED)
+    st = pt.last_stats
+    owner = madist.tile_owner(C5_W, C5_H, C5_WORLD)
+    mine = owner == rank
+    assert mine.sum() * C5_WORLD == pytest.approx(C5_W * C5_H, rel=0.02)
+    assert np.all(img[~mine] == 0) and np.isfinite(img).all() and np.all(img[mine][:, 3] <= spp)
+    assert np.mean(img[mine][:, 3] == spp) > 0.999  # glass without a TIR guard drops a few samples (BSDF.cpp:480-493, Technique.cpp:224)
+    assert st.num_paths == int(mine.sum()) * spp and int(mine.sum()) * spp - int(img[..., 3].sum()) == st.numeric_errors
+    assert pt.get_kernel() == ma.KERNEL_MEGA_GLOBAL and pt.last_launch().wide_nodes == 1  # >= 100 000 triangles: wide quantised nodes
+    # additivity over sample ranges on the sharded render (what the framebuffer reduce relies on)
+    parts = pt.render_rgbn(C5_W, C5_H, spp=1, seed=0x5EED, sample_offset=0).astype(np.float64) + pt.render_rgbn(C5_W, C5_H, spp=3, seed=0x5EED, sample_offset=1)
+    assert np.array_equal(parts[..., 3], img[..., 3])
+    np.testing.assert_allclose(parts, img, rtol=3e-7)
+    # windows of the frame inside this rank's tiles, against the oracle (per pixel: same paths, FP64 sum order aside)
+    orc = oracle.Oracle(clutter)
+    tiles_x = (C5_W + 31) // 32
+    for t in (rank, rank + C5_WORLD * 531, rank + C5_WORLD * 1001):
+        ty, tx = divmod(t, tiles_x)
+        win = (tx * 32 + 3, ty * 32 + 5, 24, 20)
+        x0, y0, w, h = win
+        assert mine[y0:y0 + h, x0:x0 + w].all()
+        ref = orc.render_rgbn(C5_W, C5_H, spp=spp, seed=0x5EED, window=win)
+        np.testing.assert_allclose(img[y0:y0 + h, x0:x0 + w], ref[y0:y0 + h, x0:x0 + w], rtol=1.2e-7)
+
+
+def test_c5_tile_shards_partition_the_frame_bitwise(clutter):
+    """The eight ranks' framebuffers of C5' at full resolution (1 spp) sum to the unsharded render bit for bit: every pixel has one owner."""
+    pt = ma.PathTracing(clutter)
+    whole = pt.render_rgbn(C5_W, C5_H, spp=1, seed=2)
+    total = np.zeros_like(whole)
+    paths = 0
+    for r in range(C5_WORLD):
+        pt.set_tile_shard(r, C5_WORLD)
+        part = pt.render_rgbn(C5_W, C5_H, spp=1, seed=2)
+        paths += pt.last_stats.num_paths
+        assert np.all(total[part[..., 3] > 0] == 0)  # disjoint owners
+        total += part
+    assert paths == C5_W * C5_H and np.array_equal(total.view(np.uint32), whole.view(np.uint32))

@@ -28,7 +28,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 #endif
 
-#define MI_PT_ABI_VERSION 2 /* 2: + mi_pt_render_async / mi_pt_wait / mi_pt_last_launch (additive) */
+#define MI_PT_ABI_VERSION 2 /* 2: + mi_pt_render_async / mi_pt_wait / mi_pt_wait_add / mi_pt_last_launch (additive) */
 
 /* ---- error codes (reference: C++ exceptions, runtime_assert.cpp:7-11, Scene.cpp:55-57) ---- */
 enum {
@@ -221,10 +221,18 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
  * so `--num-samples`, snapshots and `continue` (Application.cpp:226-229,245) see what they saw before.
  * Random streams depend only on (seed, pixel, sample index): rendering ahead changes nothing in the image.
  * ---------------------------------------------------------------------------------------- */
-#define MI_PT_FRAMES_IN_FLIGHT 3
+#define MI_PT_FRAMES_IN_FLIGHT 4
 int mi_pt_render_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win,
                        uint32_t spp, uint64_t seed, uint64_t sample_offset, uint64_t* ticket);
 int mi_pt_wait(mi_pt_handle* h, uint64_t ticket, const float** rgbn_sum, mi_pt_stats* stats);
+/* mi_pt_wait + Technique::_commit_images for the PT path (Technique.cpp:215-236) in one call: view[p] += dvec4(rgbn[p]) for the
+ * pixels of the frame's window, `view` being subimage_view_t's dvec4 data ([height][width][4] doubles, ImageView.hpp:10-67).
+ * The add is dealt to host threads of the library the way exec2d deals tiles (threadpool.cpp:190-233): on one core it costs as
+ * much as the frame's kernel (16 B read + 64 B read-modify-write per pixel).  MI_PT_HOST_THREADS overrides the thread count (<= 8). */
+int mi_pt_wait_add(mi_pt_handle* h, uint64_t ticket, double* view, mi_pt_stats* stats);
+/* The add alone, for a frame the caller already holds (mi_pt_render / mi_pt_wait): view[p] += dvec4(rgbn[p]) over `win`
+ * (w == 0: the whole image), on the same host threads. */
+int mi_view_add_frame(const float* rgbn, double* view, uint32_t width, uint32_t height, mi_window win);
 
 /* What the last mi_pt_render / mi_pt_render_device / mi_pt_render_async call launched (for measurement: bench.py
  * prices the launch's compulsory HBM bytes with it). */

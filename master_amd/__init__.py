@@ -84,7 +84,7 @@ class LaunchInfo(C.Structure):
                 ("partial_bytes", C.c_uint64), ("scene_bytes", C.c_uint64)]
 
 
-FRAMES_IN_FLIGHT = 3  # MI_PT_FRAMES_IN_FLIGHT
+FRAMES_IN_FLIGHT = 4  # MI_PT_FRAMES_IN_FLIGHT
 
 
 class SurfacePoint(C.Structure):
@@ -119,7 +119,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 # every symbol include/mi_pt.h declares; tests/test_abi.py checks the library exports them all
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version",
-    "mi_pt_render_async", "mi_pt_wait", "mi_pt_last_launch",
+    "mi_pt_render_async", "mi_pt_wait", "mi_pt_wait_add", "mi_view_add_frame", "mi_pt_last_launch",
     "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_tile_shard", "mi_pt_render_multi", "mi_pt_device_count", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
     "mi_bpt_render", "mi_bpt_trace_paths", "mi_bpt_set_sky",
     "mi_pt_bvh_download", "mi_pt_blob_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
@@ -147,6 +147,8 @@ def lib():
     L.mi_pt_render_device.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, vp, C.POINTER(PtStats)]
     L.mi_pt_render_async.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, C.POINTER(u64)]
     L.mi_pt_wait.argtypes = [vp, u64, C.POINTER(C.POINTER(f32)), C.POINTER(PtStats)]
+    L.mi_pt_wait_add.argtypes = [vp, u64, vp, C.POINTER(PtStats)]
+    L.mi_view_add_frame.argtypes = [vp, vp, u32, u32, Window]
     L.mi_pt_last_launch.argtypes = [vp, C.POINTER(LaunchInfo)]
     L.mi_pt_set_kernel.argtypes = [vp, C.c_int]
     L.mi_pt_set_tile_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
@@ -335,6 +337,13 @@ def rms_abs_errors(rgbn, reference_rgb):
     return r.value, a.value
 
 
+def view_add_frame(view, rgbn, window=None):
+    """Technique::_commit_images for the PT path (Technique.cpp:215-236): view += dvec4(rgbn) over the window, on the library's host threads."""
+    assert view.dtype == np.float64 and rgbn.dtype == np.float32 and view.shape == rgbn.shape and view.flags["C_CONTIGUOUS"] and rgbn.flags["C_CONTIGUOUS"]
+    h, w = view.shape[:2]
+    _check(lib().mi_view_add_frame(_ptr(rgbn), _ptr(view), w, h, Window(*window) if window else Window(0, 0, 0, 0)))
+
+
 def save_exr(path, rgbn, metadata=None):
     """save_exr (exr.cpp:177-232): channels R,G,B,denom + string attributes."""
     rgbn = np.ascontiguousarray(rgbn, np.float32)
@@ -443,6 +452,13 @@ class PathTracing:
         a = np.ctypeslib.as_array(p, self._frame_shape)
         return a.copy() if copy else a
 
+    def wait_add(self, ticket, view):
+        """mi_pt_wait_add: wait for the frame and add it to the float64 [H][W][4] view (Technique::_commit_images) on the library's host threads."""
+        assert view.dtype == np.float64 and view.flags["C_CONTIGUOUS"] and view.shape == self._frame_shape
+        st = PtStats()
+        _check(lib().mi_pt_wait_add(self._h, ticket, _ptr(view), C.byref(st)))
+        self.last_stats = st
+
     def last_launch(self):
         li = LaunchInfo()
         _check(lib().mi_pt_last_launch(self._h, C.byref(li)))
@@ -458,8 +474,7 @@ class PathTracing:
         for k in range(min(FRAMES_IN_FLIGHT, n_frames)):
             tickets.append(self.render_async(w, h, 1, seed, first + k, camera_id, window))
         for k in range(n_frames):
-            rgbn = self.wait(tickets[k], copy=False)
-            view += rgbn  # _commit_images (Technique.cpp:222-226)
+            self.wait_add(tickets[k], view)  # _commit_images (Technique.cpp:222-226)
             st.num_samples += 1
             st.num_basic_rays += self.last_stats.num_basic_rays
             st.num_shadow_rays += self.last_stats.num_shadow_rays

@@ -66,10 +66,13 @@ struct mi_pt_handle {
     float* d_rgbn = nullptr; size_t d_bytes = 0;
     float* h_rgbn = nullptr; size_t h_bytes = 0;
     unsigned long long* h_counters = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_counters = nullptr, ev_copied = nullptr;
+    hipStream_t stream = nullptr;                       // frames of different slots overlap on the device (a 512 x 512 frame is 1.3 rounds of waves)
+    double* partial = nullptr; size_t partial_bytes = 0;
+    unsigned long long* d_counters = nullptr;
+    uint32_t width = 0, height = 0; mi_window win{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_copied = nullptr;
     uint64_t ticket = 0; bool pending = false; bool launched = false;
   } slots[MI_PT_FRAMES_IN_FLIGHT];
-  hipStream_t copy_stream = nullptr;
   uint64_t next_ticket = 1;
   mi_pt_launch_info last{};
 };
@@ -401,9 +404,11 @@ void mi_pt_destroy(mi_pt_handle* h) {
     if (fs.d_rgbn) hipFree(fs.d_rgbn);
     if (fs.h_rgbn) hipHostFree(fs.h_rgbn);
     if (fs.h_counters) hipHostFree(fs.h_counters);
-    for (hipEvent_t e : {fs.ev0, fs.ev1, fs.ev2, fs.ev_counters, fs.ev_copied}) if (e) hipEventDestroy(e);
+    if (fs.partial) hipFree(fs.partial);
+    if (fs.d_counters) hipFree(fs.d_counters);
+    if (fs.stream) hipStreamDestroy(fs.stream);
+    for (hipEvent_t e : {fs.ev0, fs.ev1, fs.ev2, fs.ev_copied}) if (e) hipEventDestroy(e);
   }
-  if (h->copy_stream) hipStreamDestroy(h->copy_stream);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -434,10 +439,11 @@ int mi_pt_get_kernel(mi_pt_handle* h) {
 
 namespace {
 // counters and event times of the megakernel launch last recorded on `stream` (waits for it)
-struct EventSet { hipEvent_t ev0, ev1, ev2; };
+// what one render call launches into: timing events, the FP64 partial-sum buffer and the counters (the handle's own, or a frame slot's)
+struct EventSet { hipEvent_t ev0, ev1, ev2; double** partial; size_t* partial_bytes; unsigned long long* counters; };
 int collect_stats(mi_pt_handle* h, hipStream_t stream, mi_pt_stats* stats, const EventSet& ev) {
   unsigned long long c[24];
-  HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(c, ev.counters, sizeof c, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   float t01 = 0.0f, t02 = 0.0f;
   HIP_TRY(hipEventElapsedTime(&t01, ev.ev0, ev.ev1));
@@ -493,22 +499,22 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     rc = wf_prepare(h, uint32_t(per_sample * R), w);
     if (rc) return rc;
     w.per_sample = uint32_t(per_sample); w.R = uint32_t(R); w.list = 0; w.n_items = 0;
-    rc = ensure(reinterpret_cast<void**>(&h->partial), &h->partial_bytes, size_t(width) * height * 32);
+    rc = ensure(reinterpret_cast<void**>(ev.partial), ev.partial_bytes, size_t(width) * height * 32);
     if (rc) return rc;
-    p.partial = h->partial; p.counters = h->d_counters; p.n_chunks = 1; p.chunk_spp = spp;
+    p.partial = (*ev.partial); p.counters = ev.counters; p.n_chunks = 1; p.chunk_spp = spp;
     p.spp = spp; p.seed = seed; p.sample_offset = sample_offset;
-    HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(ev.counters, 0, 32 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(ev.ev0, stream));
-    HIP_TRY(hipMemsetAsync(h->partial, 0, size_t(width) * height * 32, stream));
+    HIP_TRY(hipMemsetAsync((*ev.partial), 0, size_t(width) * height * 32, stream));
     h->wf_iterations = 0;
     h->last.kernel = MI_PT_KERNEL_WAVEFRONT; h->last.n_chunks = 1; h->last.chunk_spp = spp; h->last.partial_bytes = uint64_t(width) * height * 32ull;
     HIP_TRY(mi::wf_run(p, w, h->instrumented, stream, &h->wf_iterations));
     HIP_TRY(hipEventRecord(ev.ev1, stream));
-    HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, 1, stream));
+    HIP_TRY(mi::launch_finalize((*ev.partial), rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, 1, stream));
     HIP_TRY(hipEventRecord(ev.ev2, stream));
     if (stats) {
       unsigned long long c[24];
-      HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(c, ev.counters, sizeof c, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       float t01 = 0.0f, t02 = 0.0f;
       HIP_TRY(hipEventElapsedTime(&t01, ev.ev0, ev.ev1));
@@ -541,13 +547,13 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   const uint64_t n_blocks = (n_waves + mi::kWavesPerBlock - 1) / mi::kWavesPerBlock;
   if (n_blocks > 0x7FFFFFFFull) return fail(MI_ERR_UNSUPPORTED, "render too large for one launch");
 
-  rc = ensure(reinterpret_cast<void**>(&h->partial), &h->partial_bytes, size_t(p.n_chunks) * width * height * 32);
+  rc = ensure(reinterpret_cast<void**>(ev.partial), ev.partial_bytes, size_t(p.n_chunks) * width * height * 32);
   if (rc) return rc;
-  p.partial = h->partial;
-  p.counters = h->d_counters;
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), stream));
+  p.partial = (*ev.partial);
+  p.counters = ev.counters;
+  HIP_TRY(hipMemsetAsync(ev.counters, 0, 32 * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ev.ev0, stream));
-  if (sharded) HIP_TRY(hipMemsetAsync(h->partial, 0, size_t(p.n_chunks) * width * height * 32, stream));  // pixels of other ranks' tiles
+  if (sharded) HIP_TRY(hipMemsetAsync((*ev.partial), 0, size_t(p.n_chunks) * width * height * 32, stream));  // pixels of other ranks' tiles
   HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), false, h->instrumented, uint32_t(n_blocks), stream));
   {
     mi_pt_launch_info& li = h->last;
@@ -559,7 +565,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
   }
   HIP_TRY(hipEventRecord(ev.ev1, stream));
-  HIP_TRY(mi::launch_finalize(h->partial, rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
+  HIP_TRY(mi::launch_finalize((*ev.partial), rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
   HIP_TRY(hipEventRecord(ev.ev2, stream));
   if (stats) return collect_stats(h, stream, stats, ev);
   return MI_OK;
@@ -570,7 +576,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
 int mi_pt_render_device(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp,
                         uint64_t seed, uint64_t sample_offset, float* rgbn_sum_device, void* stream_v, mi_pt_stats* stats) {
   if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render: null argument");
-  return render_impl(h, camera_id, width, height, win, spp, seed, sample_offset, rgbn_sum_device, stream_v, stats, EventSet{h->ev0, h->ev1, h->ev2});
+  return render_impl(h, camera_id, width, height, win, spp, seed, sample_offset, rgbn_sum_device, stream_v, stats, EventSet{h->ev0, h->ev1, h->ev2, &h->partial, &h->partial_bytes, h->d_counters});
 }
 
 int mi_pt_last_launch(mi_pt_handle* h, mi_pt_launch_info* out) {
@@ -587,11 +593,12 @@ int mi_pt_render_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint
   auto& fs = h->slots[h->next_ticket % MI_PT_FRAMES_IN_FLIGHT];
   if (fs.pending) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_async: " + std::to_string(MI_PT_FRAMES_IN_FLIGHT) + " frames are pending; call mi_pt_wait for ticket " + std::to_string(fs.ticket) + " first");
   const size_t bytes = size_t(width) * height * 16;
-  if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   if (!fs.ev0) {
+    HIP_TRY(hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&fs.ev0)); HIP_TRY(hipEventCreate(&fs.ev1)); HIP_TRY(hipEventCreate(&fs.ev2));
-    HIP_TRY(hipEventCreateWithFlags(&fs.ev_counters, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&fs.ev_copied, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&fs.ev_copied, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&fs.h_counters), 32 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fs.d_counters), 32 * sizeof(unsigned long long)));
   }
   int rc = ensure(reinterpret_cast<void**>(&fs.d_rgbn), &fs.d_bytes, bytes);
   if (rc) return rc;
@@ -601,30 +608,34 @@ int mi_pt_render_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint
     if (hipHostMalloc(reinterpret_cast<void**>(&fs.h_rgbn), bytes, hipHostMallocDefault) != hipSuccess) return fail(MI_ERR_OUT_OF_MEMORY, "pinned host framebuffer");
     fs.h_bytes = bytes;
   }
-  // the frame's kernels on the render stream (no host synchronisation), its counters behind them; the framebuffer crosses PCIe on
-  // the copy stream, so the next frame's kernels do not wait for it
-  rc = render_impl(h, camera_id, width, height, win, spp, seed, sample_offset, fs.d_rgbn, h->stream, nullptr, EventSet{fs.ev0, fs.ev1, fs.ev2});
+  // Everything of the frame goes to the slot's own stream, nothing synchronises with the host: counters reset, path kernel, finalize,
+  // counters and framebuffer to pinned host memory.  Slots have their own partial-sum buffers and counters, so the frames of
+  // different slots overlap on the device — one 512 x 512 frame is 4 096 waves, 1.3 rounds of what the chip holds.
+  // (The wavefront pipeline keeps its path state in one arena per handle: its frames share the handle's stream and run in order.)
+  hipStream_t stream = h->kernel_choice == MI_PT_KERNEL_WAVEFRONT ? h->stream : fs.stream;
+  rc = render_impl(h, camera_id, width, height, win, spp, seed, sample_offset, fs.d_rgbn, stream, nullptr,
+                   EventSet{fs.ev0, fs.ev1, fs.ev2, &fs.partial, &fs.partial_bytes, fs.d_counters});
   if (rc) return rc;
   fs.launched = h->last.n_blocks != 0 || h->kernel_choice == MI_PT_KERNEL_WAVEFRONT;
-  HIP_TRY(hipMemcpyAsync(fs.h_counters, h->d_counters, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipEventRecord(fs.ev_counters, h->stream));
-  HIP_TRY(hipStreamWaitEvent(h->copy_stream, fs.ev_counters, 0));
-  HIP_TRY(hipMemcpyAsync(fs.h_rgbn, fs.d_rgbn, bytes, hipMemcpyDeviceToHost, h->copy_stream));
-  HIP_TRY(hipEventRecord(fs.ev_copied, h->copy_stream));
+  if (fs.launched) HIP_TRY(hipMemcpyAsync(fs.h_counters, fs.d_counters, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(fs.h_rgbn, fs.d_rgbn, bytes, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipEventRecord(fs.ev_copied, stream));
+  if (win.w == 0 || win.h == 0) { win.x0 = 0; win.y0 = 0; win.w = width; win.h = height; }
+  fs.width = width; fs.height = height; fs.win = win;
   fs.ticket = h->next_ticket++;
   fs.pending = true;
   *ticket = fs.ticket;
   return MI_OK;
 }
 
-int mi_pt_wait(mi_pt_handle* h, uint64_t ticket, const float** rgbn_sum, mi_pt_stats* stats) {
-  if (!h || !rgbn_sum) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait: null argument");
+namespace {
+int wait_slot(mi_pt_handle* h, uint64_t ticket, mi_pt_handle::FrameSlot** out, mi_pt_stats* stats) {
   auto& fs = h->slots[ticket % MI_PT_FRAMES_IN_FLIGHT];
   if (!fs.pending || fs.ticket != ticket) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait: ticket " + std::to_string(ticket) + " is not pending");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipEventSynchronize(fs.ev_copied));
   fs.pending = false;
-  *rgbn_sum = fs.h_rgbn;
+  *out = &fs;
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
     if (fs.launched) {
@@ -636,6 +647,25 @@ int mi_pt_wait(mi_pt_handle* h, uint64_t ticket, const float** rgbn_sum, mi_pt_s
       stats->trace_ms = t01; stats->gpu_ms = t02;
     }
   }
+  return MI_OK;
+}
+}  // namespace
+
+int mi_pt_wait(mi_pt_handle* h, uint64_t ticket, const float** rgbn_sum, mi_pt_stats* stats) {
+  if (!h || !rgbn_sum) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait: null argument");
+  mi_pt_handle::FrameSlot* fs = nullptr;
+  const int rc = wait_slot(h, ticket, &fs, stats);
+  if (rc) return rc;
+  *rgbn_sum = fs->h_rgbn;
+  return MI_OK;
+}
+
+int mi_pt_wait_add(mi_pt_handle* h, uint64_t ticket, double* view, mi_pt_stats* stats) {
+  if (!h || !view) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait_add: null argument");
+  mi_pt_handle::FrameSlot* fs = nullptr;
+  const int rc = wait_slot(h, ticket, &fs, stats);
+  if (rc) return rc;
+  mi::add_frame_to_view(fs->h_rgbn, view, fs->width, fs->win.x0, fs->win.y0, fs->win.w, fs->win.h);
   return MI_OK;
 }
 
@@ -705,7 +735,7 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
       if (hipMemcpy(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MI_ERR_NO_DEVICE, "counter copy failed"); continue; }
       one.num_basic_rays = c[0]; one.num_shadow_rays = c[1]; one.numeric_errors = c[2]; one.num_paths = c[3];
     } else {
-      const int r2 = collect_stats(h, h->stream, &one, EventSet{h->ev0, h->ev1, h->ev2});
+      const int r2 = collect_stats(h, h->stream, &one, EventSet{h->ev0, h->ev1, h->ev2, &h->partial, &h->partial_bytes, h->d_counters});
       if (r2 != MI_OK) { rc = r2; continue; }
     }
     total.num_basic_rays += one.num_basic_rays; total.num_shadow_rays += one.num_shadow_rays; total.numeric_errors += one.numeric_errors;

@@ -35,6 +35,9 @@ int load_blend(const char* path, const mi_blend_options* opts, SceneData& out); 
 int save_miscene(const SceneData& s, const char* path);
 int load_miscene(const char* path, SceneData& s);
 void camera_setup(const mi_camera& c, float aspect, mi_camera_frame& out);
+// Technique::_commit_images for the PT path (Technique.cpp:215-236): view[p] += dvec4(rgbn[p]) over the window, rows dealt to the
+// library's host threads (the reference deals its frame to a thread pool too, threadpool.cpp:190-233)
+void add_frame_to_view(const float* rgbn, double* view, uint32_t width, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h);
 
 }  // namespace mi
 

@@ -148,3 +148,17 @@ def test_c_example_on_several_devices_writes_the_same_image(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(ma.load_exr(out))
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+def test_view_add_frame_is_commit_images():
+    """mi_view_add_frame (and mi_pt_wait_add behind it): view[p] += dvec4(rgbn[p]) over the window (Technique.cpp:215-236), rows dealt to host threads."""
+    rng = np.random.default_rng(1)
+    for (w, h, win) in ((512, 512, None), (100, 70, (5, 3, 66, 64)), (33, 17, None), (1, 1, None), (257, 129, (256, 0, 1, 129))):
+        view = rng.normal(size=(h, w, 4)); f = rng.normal(size=(h, w, 4)).astype(np.float32)
+        ref = view.copy()
+        x0, y0, ww, hh = win if win else (0, 0, w, h)
+        ref[y0:y0 + hh, x0:x0 + ww] += f[y0:y0 + hh, x0:x0 + ww]
+        ma.view_add_frame(view, f, win)
+        assert np.array_equal(view, ref)
+    with pytest.raises(ma.MiError):
+        ma.view_add_frame(np.zeros((4, 4, 4)), np.zeros((4, 4, 4), np.float32), (2, 2, 3, 3))

@@ -98,9 +98,12 @@ def test_c5_workload_tile_shard_properties_and_windows_against_oracle(clutter, r
     assert st.num_paths == int(mine.sum()) * spp and int(mine.sum()) * spp - int(img[..., 3].sum()) == st.numeric_errors
     assert pt.get_kernel() == ma.KERNEL_MEGA_GLOBAL and pt.last_launch().wide_nodes == 1  # >= 100 000 triangles: wide quantised nodes
     # additivity over sample ranges on the sharded render (what the framebuffer reduce relies on)
-    parts = pt.render_rgbn(C5_W, C5_H, spp=1, seed=0x5EED, sample_offset=0).astype(np.float64) + pt.render_rgbn(C5_W, C5_H, spp=3, seed=0x5EED, sample_offset=1)
+    p1, p3 = pt.render_rgbn(C5_W, C5_H, spp=1, seed=0x5EED, sample_offset=0).astype(np.float64), pt.render_rgbn(C5_W, C5_H, spp=3, seed=0x5EED, sample_offset=1)
+    parts = p1 + p3
     assert np.array_equal(parts[..., 3], img[..., 3])
-    np.testing.assert_allclose(parts, img, rtol=3e-7)
+    # each framebuffer is one FP32 cast of an FP64 sum; a mirror seen from behind its shading normal contributes with a negative
+    # sign (ReflectionBSDF: throughput 1 / omega.y, BSDF.cpp:450-465), so the bound is relative to the parts, not to their sum
+    assert np.all(np.abs(parts - img) <= 1.2e-7 * (np.abs(p1) + np.abs(p3) + np.abs(img)))
     # windows of the frame inside this rank's tiles, against the oracle (per pixel: same paths, FP64 sum order aside)
     orc = oracle.Oracle(clutter)
     tiles_x = (C5_W + 31) // 32

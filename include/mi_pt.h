@@ -28,7 +28,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
 #endif
 
-#define MI_PT_ABI_VERSION 2 /* 2: + mi_pt_render_async / mi_pt_wait / mi_pt_wait_add / mi_pt_last_launch (additive) */
+#define MI_PT_ABI_VERSION 2 /* 2: + mi_pt_render_frames_async / mi_pt_render_async / mi_pt_wait / mi_pt_wait_add / mi_view_add_frame / mi_pt_last_launch (additive) */
 
 /* ---- error codes (reference: C++ exceptions, runtime_assert.cpp:7-11, Scene.cpp:55-57) ---- */
 enum {
@@ -210,18 +210,23 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
  * when it saves (Application::_save) or compares with a reference image.  A frame of 512 x 512 is 4 096 waves: called
  * synchronously (mi_pt_render, spp = 1) the GPU idles while the host copies 16 B per pixel and adds it to the view.
  *
- * mi_pt_render_async enqueues the frame (samples [sample_offset, sample_offset + spp) of the window, exactly as
- * mi_pt_render) and returns at once with a ticket; the result lands in a pinned host buffer owned by the handle.
- * mi_pt_wait blocks until that frame is complete and hands out its buffer ([height][width][4] floats, row 0 = bottom)
- * and statistics.  Up to MI_PT_FRAMES_IN_FLIGHT frames may be pending; a buffer stays valid until
- * MI_PT_FRAMES_IN_FLIGHT further frames have been enqueued.  Frames complete in the order they were enqueued; every
- * ticket must be waited for before its slot is reused (mi_pt_render_async fails with MI_ERR_INVALID_ARGUMENT otherwise).
- * The adapter's render(k) = wait(frame k) -> view += dvec4(rgbn) -> enqueue(frame k + MI_PT_FRAMES_IN_FLIGHT): frame
- * k + 1 renders and crosses PCIe while the host adds frame k, and the view after call k holds exactly frames 0..k,
- * so `--num-samples`, snapshots and `continue` (Application.cpp:226-229,245) see what they saw before.
- * Random streams depend only on (seed, pixel, sample index): rendering ahead changes nothing in the image.
+ * mi_pt_render_frames_async enqueues `n_frames` consecutive frames (samples first_sample .. first_sample + n_frames - 1 of the
+ * window, ONE sample per pixel each, exactly what n_frames calls of mi_pt_render(spp = 1) return) as ONE launch and returns at
+ * once with one ticket per frame; inside the launch a wave that has finished a path of frame f starts the same pixel's path of
+ * frame f + 1, so the chip stays full.  The frames land in pinned host buffers owned by the handle.  mi_pt_wait blocks until
+ * the ticket's frame is complete and hands out its buffer ([height][width][4] floats, row 0 = bottom) and its statistics (ray and
+ * error counts are exact per frame; the device time of the launch is shared evenly by its frames).  mi_pt_render_async is the
+ * same for ONE frame of `spp` samples.  Up to MI_PT_BATCHES_IN_FLIGHT calls may be pending; every ticket of a call must be
+ * waited for before its slot is reused (the enqueue fails with MI_ERR_INVALID_ARGUMENT otherwise), and a buffer stays valid
+ * until then.  The adapter's loop with batches of B frames: render(k) = [k mod B == 0: enqueue batch k / B + 2] ->
+ * wait_add(frame k): the next batches render and cross PCIe while the host adds the frames of this one, and the view after call
+ * k holds exactly frames 0..k, so `--num-samples`, snapshots and `continue` (Application.cpp:226-229,245) see what they saw
+ * before.  Random streams depend only on (seed, pixel, sample index): rendering ahead changes nothing in the image.
  * ---------------------------------------------------------------------------------------- */
-#define MI_PT_FRAMES_IN_FLIGHT 4
+#define MI_PT_MAX_FRAMES_PER_BATCH 8
+#define MI_PT_BATCHES_IN_FLIGHT 3
+int mi_pt_render_frames_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win,
+                              uint32_t n_frames, uint64_t seed, uint64_t first_sample, uint64_t* tickets /*[n_frames]*/);
 int mi_pt_render_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win,
                        uint32_t spp, uint64_t seed, uint64_t sample_offset, uint64_t* ticket);
 int mi_pt_wait(mi_pt_handle* h, uint64_t ticket, const float** rgbn_sum, mi_pt_stats* stats);
@@ -245,6 +250,8 @@ typedef struct mi_pt_launch_info {
   uint32_t wide_nodes;      /* 0 = 32-byte quantised binary nodes, 1 = 64-byte wide nodes, 2 = 64-byte float nodes */
   uint32_t features;        /* kFeat* bits of the kernel variant                                              */
   uint32_t lds_tables;      /* 1: materials, lights and the light CDF were staged into LDS by every workgroup */
+  uint32_t frame_tiles_per_wave; /* > 0: frame mode (spp == 1): paths write the framebuffer directly, a wave owns this many 8x8 tiles */
+  uint32_t frames;               /* frame mode: frames of the launch */
   uint64_t partial_bytes;   /* FP64 partial sums written by the path kernel and read by pt_finalize           */
   uint64_t scene_bytes;     /* scene blob (+ quantised node copies) resident in HBM                           */
 } mi_pt_launch_info;

@@ -81,10 +81,10 @@ class PtStats(C.Structure):
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_uint32), ("n_blocks", C.c_uint32), ("n_chunks", C.c_uint32), ("chunk_spp", C.c_uint32),
                 ("lds_bytes", C.c_uint32), ("wide_nodes", C.c_uint32), ("features", C.c_uint32), ("lds_tables", C.c_uint32),
-                ("partial_bytes", C.c_uint64), ("scene_bytes", C.c_uint64)]
+                ("frame_tiles_per_wave", C.c_uint32), ("frames", C.c_uint32), ("partial_bytes", C.c_uint64), ("scene_bytes", C.c_uint64)]
 
 
-FRAMES_IN_FLIGHT = 4  # MI_PT_FRAMES_IN_FLIGHT
+MAX_FRAMES_PER_BATCH, BATCHES_IN_FLIGHT = 8, 3  # MI_PT_MAX_FRAMES_PER_BATCH, MI_PT_BATCHES_IN_FLIGHT
 
 
 class SurfacePoint(C.Structure):
@@ -119,7 +119,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 # every symbol include/mi_pt.h declares; tests/test_abi.py checks the library exports them all
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version",
-    "mi_pt_render_async", "mi_pt_wait", "mi_pt_wait_add", "mi_view_add_frame", "mi_pt_last_launch",
+    "mi_pt_render_frames_async", "mi_pt_render_async", "mi_pt_wait", "mi_pt_wait_add", "mi_view_add_frame", "mi_pt_last_launch",
     "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_tile_shard", "mi_pt_render_multi", "mi_pt_device_count", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
     "mi_bpt_render", "mi_bpt_trace_paths", "mi_bpt_set_sky",
     "mi_pt_bvh_download", "mi_pt_blob_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
@@ -146,6 +146,7 @@ def lib():
     L.mi_pt_render.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, C.POINTER(PtStats)]
     L.mi_pt_render_device.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, vp, vp, C.POINTER(PtStats)]
     L.mi_pt_render_async.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, C.POINTER(u64)]
+    L.mi_pt_render_frames_async.argtypes = [vp, u32, u32, u32, Window, u32, u64, u64, C.POINTER(u64)]
     L.mi_pt_wait.argtypes = [vp, u64, C.POINTER(C.POINTER(f32)), C.POINTER(PtStats)]
     L.mi_pt_wait_add.argtypes = [vp, u64, vp, C.POINTER(PtStats)]
     L.mi_view_add_frame.argtypes = [vp, vp, u32, u32, Window]
@@ -437,12 +438,20 @@ class PathTracing:
         return self.last_stats
 
     def render_async(self, width, height, spp=1, seed=0, sample_offset=0, camera_id=0, window=None):
-        """mi_pt_render_async: enqueue a frame, returns its ticket (up to FRAMES_IN_FLIGHT may be pending)."""
+        """mi_pt_render_async: enqueue ONE frame of `spp` samples, returns its ticket (up to BATCHES_IN_FLIGHT calls may be pending)."""
         t = C.c_uint64()
         win = Window(*window) if window else Window(0, 0, 0, 0)
         _check(lib().mi_pt_render_async(self._h, camera_id, width, height, win, spp, seed, sample_offset, C.byref(t)))
         self._frame_shape = (height, width, 4)
         return t.value
+
+    def render_frames_async(self, width, height, n_frames, seed=0, first_sample=0, camera_id=0, window=None):
+        """mi_pt_render_frames_async: enqueue `n_frames` consecutive one-sample frames as ONE launch, returns their tickets."""
+        t = (C.c_uint64 * n_frames)()
+        win = Window(*window) if window else Window(0, 0, 0, 0)
+        _check(lib().mi_pt_render_frames_async(self._h, camera_id, width, height, win, n_frames, seed, first_sample, t))
+        self._frame_shape = (height, width, 4)
+        return list(t)
 
     def wait(self, ticket, copy=True):
         """mi_pt_wait: the frame's [H][W][4] sums (a view of the handle's pinned buffer unless copy) and its statistics."""
@@ -464,22 +473,30 @@ class PathTracing:
         _check(lib().mi_pt_last_launch(self._h, C.byref(li)))
         return li
 
-    def render_frames(self, view, n_frames, seed=0, camera_id=0, window=None):
-        """The adapter's frame loop (integration/GpuPathTracing.cpp): `n_frames` calls of Technique::render at spp = 1 with
-        FRAMES_IN_FLIGHT frames pending — frame k + 1 renders while the host adds frame k to the dvec4 view."""
+    def render_frames(self, view, n_frames, seed=0, camera_id=0, window=None, batch=4):
+        """The adapter's frame loop (integration/GpuPathTracing.cpp): `n_frames` calls of Technique::render at one sample per call, with
+        batches of `batch` frames in flight — the next batches render while the host adds the frames of this one to the dvec4 view."""
         h, w = view.shape[:2]
         st = self._statistics
         first = st.num_samples
-        tickets = []
-        for k in range(min(FRAMES_IN_FLIGHT, n_frames)):
-            tickets.append(self.render_async(w, h, 1, seed, first + k, camera_id, window))
+        n_batches = (n_frames + batch - 1) // batch
+        tickets = {}
+
+        def enqueue(j):
+            if j < n_batches:
+                k0 = j * batch
+                tickets[j] = self.render_frames_async(w, h, min(batch, n_frames - k0), seed, first + k0, camera_id, window)
+
+        for j in range(BATCHES_IN_FLIGHT - 1):
+            enqueue(j)
         for k in range(n_frames):
-            self.wait_add(tickets[k], view)  # _commit_images (Technique.cpp:222-226)
+            j, f = divmod(k, batch)
+            if f == 0:
+                enqueue(j + BATCHES_IN_FLIGHT - 1)
+            self.wait_add(tickets[j][f], view)  # _commit_images (Technique.cpp:222-226)
             st.num_samples += 1
             st.num_basic_rays += self.last_stats.num_basic_rays
             st.num_shadow_rays += self.last_stats.num_shadow_rays
-            if k + FRAMES_IN_FLIGHT < n_frames:
-                tickets.append(self.render_async(w, h, 1, seed, first + k + FRAMES_IN_FLIGHT, camera_id, window))
 
     def render(self, view, seed=0, camera_id=0, reference=None, window=None, spp=1):
         """Technique::render (Technique.cpp:15-77): adds `spp` frames (default 1, as the reference) to

@@ -16,7 +16,7 @@ hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qno
                           hipStream_t stream);
 
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene);
-hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream);
+hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bool count, uint32_t n_blocks, hipStream_t stream);  // mode: 0 image, 1 list, 2 frame (one sample per pixel)
 hipError_t launch_finalize(const double* partial, float* rgbn, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w,
                            uint32_t h, uint32_t n_chunks, hipStream_t stream);
 hipError_t launch_intersect(const SceneView& sv, bool wide, uint32_t stack_entries, uint32_t n, const mi_surface_point* origins, const float* dirs,

@@ -74,7 +74,14 @@ struct RenderParams {
   // list mode (mi_pt_trace_paths)
   const uint32_t* list_xy; const uint64_t* list_sample; uint32_t list_n;
   float* list_radiance; uint32_t* list_counts;
+  // frame mode (one sample per pixel): the FP32 framebuffer the paths write to, and the 8x8 tiles one wave regenerates over
+  float4* frame_rgbn; uint32_t frame_tiles_per_wave;
+  uint32_t frame_count;    // frames of the launch (consecutive samples sample_offset ..), each into its own framebuffer; <= kMaxFramesPerLaunch
+  uint32_t frame_stride;   // float4 elements between the framebuffers of consecutive frames (width * height)
+  uint32_t frame_chunk;    // consecutive frames of the launch one wave owns (of its tiles): pool of a wave = 64 * frame_tiles_per_wave * frame_chunk paths
 };
+constexpr uint32_t kMaxFramesPerLaunch = 16;  // per-wave frame counts live in 64 LDS words
+constexpr uint32_t kCounterWords = 32 + 4 * kMaxFramesPerLaunch;  // counters buffer: totals / instrumentation [0, 32), per-frame counts [32 + 4 f ..]
 
 // Origin of wave tile `tile` (8x8 pixels).  Unsharded: row-major over the window.  Sharded: the rank's k-th 32x32 tile
 // (Technique.cpp:167) is tile k * world + rank of the window, and holds 16 wave tiles.

@@ -60,8 +60,16 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 #define MI_WAVES_HBM_LARGE 7  // scenes of >= kLargeSceneTris triangles: latency-bound gathers want occupancy (atrium +12 %, clutter +4 % over 5 waves); -11 % on a 2 k-triangle scene
 #endif
 
-template <bool LDS_SCENE, bool LIST, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true>
+// MODE: 0 = image (tile x sample chunk per wave, per-pixel FP64 sums in LDS), 1 = list (mi_pt_trace_paths), 2 = frame: ONE sample per
+// pixel, the cadence of the reference (Application.cpp:66: one Technique::render per sample).  A frame has nothing to accumulate, so
+// a path's radiance goes straight into the FP32 framebuffer as (r, g, b, 1) — no LDS sums, no partial buffer, no pt_finalize — and a
+// wave owns its 8x8 tiles (RenderParams::frame_tiles_per_wave) in ALL the frames of the launch (frame_count consecutive samples, each
+// into its own framebuffer), so that dead lanes regenerate onto the same pixels of the next frame: with one frame of one tile per wave
+// the waves run as long as their longest path while their lanes die (0.29 ms per 512 x 512 frame against 0.10 ms per frame inside a
+// 1024-spp launch).  Ray / error counts are kept per frame (LDS atomics at path end; Technique::render fills statistics per frame).
+template <bool LDS_SCENE, int MODE, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true>
 __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParams p) {
+  constexpr bool LIST = MODE == 1, FRAME = MODE == 2, IMAGE = MODE == 0;
   extern __shared__ float4 smem[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -82,7 +90,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   double* acc_g = acc_r + 64;
   double* acc_b = acc_g + 64;
   uint32_t* acc_n = reinterpret_cast<uint32_t*>(acc_b + 64);
-  if (!LIST) { acc_r[lane] = 0.0; acc_g[lane] = 0.0; acc_b[lane] = 0.0; acc_n[lane] = 0u; }
+  if (IMAGE) { acc_r[lane] = 0.0; acc_g[lane] = 0.0; acc_b[lane] = 0.0; acc_n[lane] = 0u; }
+  if (FRAME) acc_n[lane] = 0u;  // per-frame counts of this wave: [frame][closest-hit rays, shadow rays, numeric errors, paths]
   __syncthreads();
 
   // ---- which pool does this wave own?  XCD-aware: workgroups are dealt round-robin over the 8
@@ -100,6 +109,17 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
     pool_next = logical_wave * per_wave;
     pool_end = pool_next + per_wave < p.list_n ? pool_next + per_wave : p.list_n;
     if (pool_next > pool_end) pool_next = pool_end;
+  } else if (FRAME) {
+    // wave = (group of frame_tiles_per_wave tiles) x (chunk of frame_chunk consecutive frames of the launch); consecutive waves share the tiles.
+    // Measured on C2 (tools/spp_scaling.py, profiles/r02/cadence.txt): a launch wants >= 2-3 rounds of waves AND >= 2 paths per lane.
+    const uint32_t n_fc = (p.frame_count + p.frame_chunk - 1u) / p.frame_chunk, n_tiles = p.tiles_x * p.tiles_y;
+    const uint32_t group = logical_wave / n_fc, fc = logical_wave - group * n_fc;
+    chunk = fc * p.frame_chunk;                                                              // first frame of the wave
+    tile_y0 = p.frame_count - chunk < p.frame_chunk ? p.frame_count - chunk : p.frame_chunk;  // its frames
+    tile_x0 = group * p.frame_tiles_per_wave;                                                // first tile of the wave
+    const uint32_t tcount = tile_x0 < n_tiles ? (n_tiles - tile_x0 < p.frame_tiles_per_wave ? n_tiles - tile_x0 : p.frame_tiles_per_wave) : 0u;
+    pool_next = 0;
+    pool_end = 64u * tcount * tile_y0;
   } else {
     const uint32_t n_tiles = p.tiles_x * p.tiles_y;
     const uint32_t tile = logical_wave / p.n_chunks;
@@ -165,6 +185,16 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
           if (LIST) {
             px = p.list_xy[2 * item]; py = p.list_xy[2 * item + 1]; sample = p.list_sample[item];
             item_id = item;
+          } else if (FRAME) {
+            // 64 consecutive items = one tile in one frame; the next 64 = the same tile in the next frame
+            const uint32_t slab = item >> 6, tl = slab / tile_y0, frame = chunk + (slab - tl * tile_y0);
+            uint32_t fx0, fy0;
+            tile_origin(p, tile_x0 + tl, fx0, fy0);
+            px = fx0 + (item & 7u); py = fy0 + ((item >> 3) & 7u);
+            sample = p.sample_offset + frame;
+            ok = px < p.win_x0 + p.win_w && py < p.win_y0 + p.win_h;
+            item_id = frame * p.frame_stride + py * p.width + px;
+            ps_pix = frame << 26;
           } else {
             const uint32_t pix = item & 63u;
             ps_pix = pix << 26;
@@ -305,6 +335,12 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         if (LIST) {
           p.list_radiance[3 * item_id] = radiance.x; p.list_radiance[3 * item_id + 1] = radiance.y; p.list_radiance[3 * item_id + 2] = radiance.z;
           if (p.list_counts) { p.list_counts[2 * item_id] = path_basic; p.list_counts[2 * item_id + 1] = path_shadow; }
+        } else if (FRAME) {  // the pixel's only sample of this frame: (radiance, 1), or nothing counted if it is not finite
+          const bool fin = isfinite(l1norm(radiance));
+          p.frame_rgbn[item_id] = fin ? make_float4(radiance.x, radiance.y, radiance.z, 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!fin) t_err = true;
+          uint32_t* fc = acc_n + 4u * (ps_pix >> 26);  // this wave's per-frame counts: closest-hit rays, shadow rays, numeric errors, paths
+          atomicAdd(&fc[0], path_basic); atomicAdd(&fc[1], path_shadow); atomicAdd(&fc[2], fin ? 0u : 1u); atomicAdd(&fc[3], 1u);
         } else if (isfinite(l1norm(radiance))) {
           const uint32_t pix = ps_pix >> 26;
           atomicAdd(&acc_r[pix], double(radiance.x));
@@ -326,7 +362,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   }
 
   // ---- the wave's sums leave LDS once: partial[chunk][pixel] = (r, g, b, count) ----
-  if (!LIST && pool_end != 0u) {
+  if (IMAGE && pool_end != 0u) {
     const uint32_t px = tile_x0 + (lane & 7u), py = tile_y0 + (lane >> 3);
     if (px < p.win_x0 + p.win_w && py < p.win_y0 + p.win_h) {
       double* o = p.partial + (size_t(chunk) * p.width * p.height + size_t(py) * p.width + px) * 4;
@@ -334,6 +370,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
       reinterpret_cast<double2*>(o)[1] = make_double2(acc_b[lane], double(acc_n[lane]));
     }
   }
+  if (FRAME && p.counters && lane < 4u * p.frame_count && acc_n[lane]) atomicAdd(&p.counters[32u + lane], (unsigned long long)acc_n[lane]);
   const uint32_t sb_ = n_basic, ss_ = n_shadow, se_ = n_err, sp_ = n_paths;
   if (lane == 0 && p.counters) {
     if (sb_) atomicAdd(&p.counters[0], (unsigned long long)sb_);
@@ -436,26 +473,30 @@ size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
   return (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0) + size_t(p.stack_entries) * kBlock * 4 + kWavesPerBlock * kAccBytesPerWave;
 }
 
-hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, bool list, bool count, uint32_t n_blocks, hipStream_t stream) {
+hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bool count, uint32_t n_blocks, hipStream_t stream) {
   const size_t lds = pt_lds_bytes(p, lds_scene);
   void (*fn)(const RenderParams) = nullptr;
   const bool large = p.wide_nodes == 1u;
-  if (!lds_scene && p.wide_nodes == 2u) {  // full-precision 64-byte nodes from HBM: scenes whose triangles are small against the 16-bit grid
-    if (count) fn = pt_megakernel<false, false, true, MI_WAVES_HBM, 0>;
-    else fn = list ? pt_megakernel<false, true, false, MI_WAVES_HBM, 0> : pt_megakernel<false, false, false, MI_WAVES_HBM, 0>;
+  const bool list = mode == 1;
+  if (!lds_scene && p.wide_nodes == 2u && (count || list)) {  // full-precision 64-byte nodes from HBM: scenes whose triangles are small against the 16-bit grid
+    if (count) fn = pt_megakernel<false, 0, true, MI_WAVES_HBM, 0>;
+    else fn = pt_megakernel<false, 1, false, MI_WAVES_HBM, 0>;
   } else
-  if (count) fn = lds_scene ? pt_megakernel<true, false, true, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, false, true, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, false, true, MI_WAVES_HBM, 1>);
-  else if (list) fn = lds_scene ? pt_megakernel<true, true, false, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, true, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, true, false, MI_WAVES_HBM, 1>);
+  if (count) fn = lds_scene ? pt_megakernel<true, 0, true, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, 0, true, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, 0, true, MI_WAVES_HBM, 1>);
+  else if (list) fn = lds_scene ? pt_megakernel<true, 1, false, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, 1, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, 1, false, MI_WAVES_HBM, 1>);
   else {
     // the compiled feature set that covers the scene: any combination of Phong lobes and mirrors / glass with beta in {1, 2}, or everything
-#define MI_PICK4(L, W, Q, S, B) (f2 == 0 ? pt_megakernel<L, false, false, W, Q, (B) | 0, S> : f2 == 1 ? pt_megakernel<L, false, false, W, Q, (B) | 1, S> : \
-                                 f2 == 2 ? pt_megakernel<L, false, false, W, Q, (B) | 2, S> : pt_megakernel<L, false, false, W, Q, (B) | 3, S>)
-#define MI_PICK(L, W, Q, S) (feat == kFeatAll ? pt_megakernel<L, false, false, W, Q, kFeatAll, S> : (feat & kFeatLights) ? MI_PICK4(L, W, Q, S, kFeatLights) : MI_PICK4(L, W, Q, S, 0))
+#define MI_PICK4(L, M, W, Q, S, B) (f2 == 0 ? pt_megakernel<L, M, false, W, Q, (B) | 0, S> : f2 == 1 ? pt_megakernel<L, M, false, W, Q, (B) | 1, S> : \
+                                    f2 == 2 ? pt_megakernel<L, M, false, W, Q, (B) | 2, S> : pt_megakernel<L, M, false, W, Q, (B) | 3, S>)
+#define MI_PICK(L, M, W, Q, S) (feat == kFeatAll ? pt_megakernel<L, M, false, W, Q, kFeatAll, S> : (feat & kFeatLights) ? MI_PICK4(L, M, W, Q, S, kFeatLights) : MI_PICK4(L, M, W, Q, S, 0))
+#define MI_PICK_MODE(L, W, Q, S) (mode == 2 ? MI_PICK(L, 2, W, Q, S) : MI_PICK(L, 0, W, Q, S))
     const int feat = (p.features & uint32_t(kFeatPow)) ? kFeatAll : int(p.features);  // a general beta is rare: only the general variant has pow
     const int f2 = feat & 3;
-    if (lds_scene) fn = p.stack_in_lds ? MI_PICK(true, MI_WAVES_LDS, 0, false) : MI_PICK(true, MI_WAVES_LDS, 0, true);  // shallow tree: stack without the spill path
-    else if (large) fn = MI_PICK(false, MI_WAVES_HBM_LARGE, 2, true);
-    else fn = MI_PICK(false, MI_WAVES_HBM, 1, true);
+    if (lds_scene) fn = p.stack_in_lds ? MI_PICK_MODE(true, MI_WAVES_LDS, 0, false) : MI_PICK_MODE(true, MI_WAVES_LDS, 0, true);  // shallow tree: stack without the spill path
+    else if (p.wide_nodes == 2u) fn = MI_PICK_MODE(false, MI_WAVES_HBM, 0, true);
+    else if (large) fn = MI_PICK_MODE(false, MI_WAVES_HBM_LARGE, 2, true);
+    else fn = MI_PICK_MODE(false, MI_WAVES_HBM, 1, true);
+#undef MI_PICK_MODE
 #undef MI_PICK
 #undef MI_PICK4
   }

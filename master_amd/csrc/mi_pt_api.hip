@@ -61,18 +61,20 @@ struct mi_pt_handle {
   double* bpt_light = nullptr; size_t bpt_light_bytes = 0;
   float sphere[4] = {0, 0, 0, 0};
   float sky_horizon[3] = {0, 0, 0}, sky_zenith[3] = {0, 0, 0};
-  // frames in flight (mi_pt_render_async / mi_pt_wait): per slot a device framebuffer, its pinned host copy and the launch's counters
-  struct FrameSlot {
+  // frames in flight (mi_pt_render_frames_async / mi_pt_render_async / mi_pt_wait): a batch = the frames of ONE launch; per batch slot the
+  // frames' device framebuffers (contiguous), their pinned host copies, counters, partial sums and a stream of its own
+  struct BatchSlot {
     float* d_rgbn = nullptr; size_t d_bytes = 0;
     float* h_rgbn = nullptr; size_t h_bytes = 0;
-    unsigned long long* h_counters = nullptr;
-    hipStream_t stream = nullptr;                       // frames of different slots overlap on the device (a 512 x 512 frame is 1.3 rounds of waves)
+    unsigned long long* d_counters = nullptr; unsigned long long* h_counters = nullptr;
+    hipStream_t stream = nullptr;
     double* partial = nullptr; size_t partial_bytes = 0;
-    unsigned long long* d_counters = nullptr;
-    uint32_t width = 0, height = 0; mi_window win{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_copied = nullptr;
-    uint64_t ticket = 0; bool pending = false; bool launched = false;
-  } slots[MI_PT_FRAMES_IN_FLIGHT];
+    uint64_t first_ticket = 0; uint32_t n_frames = 0, pending_mask = 0;
+    uint32_t width = 0, height = 0; mi_window win{};
+    bool launched = false, per_frame_counts = false, synced = false;
+  } batches[MI_PT_BATCHES_IN_FLIGHT];
+  uint32_t next_batch = 0;
   uint64_t next_ticket = 1;
   mi_pt_launch_info last{};
 };
@@ -207,7 +209,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreate(&h->stream));
   HIP_TRY(hipEventCreate(&h->ev0)); HIP_TRY(hipEventCreate(&h->ev1)); HIP_TRY(hipEventCreate(&h->ev2));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_counters), 32 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_counters), mi::kCounterWords * sizeof(unsigned long long)));
 
   const mi::SceneData& s = h->scene;
   const uint32_t nt = uint32_t(s.indices.size() / 3), nmat = uint32_t(s.materials.size()), nl = uint32_t(s.lights.size());
@@ -399,15 +401,15 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->h_stage) hipHostFree(h->h_stage);
   if (h->ev2) hipEventDestroy(h->ev2);
-  for (auto& fs : h->slots) {
-    if (fs.pending && fs.ev_copied) (void)hipEventSynchronize(fs.ev_copied);
-    if (fs.d_rgbn) hipFree(fs.d_rgbn);
-    if (fs.h_rgbn) hipHostFree(fs.h_rgbn);
-    if (fs.h_counters) hipHostFree(fs.h_counters);
-    if (fs.partial) hipFree(fs.partial);
-    if (fs.d_counters) hipFree(fs.d_counters);
-    if (fs.stream) hipStreamDestroy(fs.stream);
-    for (hipEvent_t e : {fs.ev0, fs.ev1, fs.ev2, fs.ev_copied}) if (e) hipEventDestroy(e);
+  for (auto& bs : h->batches) {
+    if (bs.pending_mask && bs.ev_copied) (void)hipEventSynchronize(bs.ev_copied);
+    if (bs.d_rgbn) hipFree(bs.d_rgbn);
+    if (bs.h_rgbn) hipHostFree(bs.h_rgbn);
+    if (bs.h_counters) hipHostFree(bs.h_counters);
+    if (bs.partial) hipFree(bs.partial);
+    if (bs.d_counters) hipFree(bs.d_counters);
+    for (hipEvent_t e : {bs.ev0, bs.ev1, bs.ev2, bs.ev_copied}) if (e) hipEventDestroy(e);
+    if (bs.stream) hipStreamDestroy(bs.stream);
   }
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -457,8 +459,16 @@ int collect_stats(mi_pt_handle* h, hipStream_t stream, mi_pt_stats* stats, const
 }
 
 // Technique::render for `spp` frames: the launches of one call on `stream`, timed by the events of `ev`
+// n_frames > 1 (frame mode only, spp == 1): samples sample_offset .. sample_offset + n_frames - 1 as separate frames into n_frames
+// consecutive framebuffers, ONE launch (frame_mode_available() must hold)
+bool frame_mode_available(const mi_pt_handle* h) {
+  const char* e = std::getenv("MI_PT_FRAME_MODE");
+  return h->kernel_choice != MI_PT_KERNEL_WAVEFRONT && !h->instrumented && !(e && std::atoi(e) == 0);
+}
 int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp,
-                uint64_t seed, uint64_t sample_offset, float* rgbn_sum_device, void* stream_v, mi_pt_stats* stats, const EventSet& ev) {
+                uint64_t seed, uint64_t sample_offset, float* rgbn_sum_device, void* stream_v, mi_pt_stats* stats, const EventSet& ev, uint32_t n_frames = 1) {
+  if (n_frames == 0 || n_frames > mi::kMaxFramesPerLaunch || (n_frames > 1 && (spp != 1 || !frame_mode_available(h))))
+    return fail(MI_ERR_INTERNAL, "render_impl: bad frame batch");
   if (!h || !rgbn_sum_device) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render: null argument");
   if (spp == 0) return fail(MI_ERR_INVALID_ARGUMENT, "spp must be > 0");
   mi::RenderParams p;
@@ -503,7 +513,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     if (rc) return rc;
     p.partial = (*ev.partial); p.counters = ev.counters; p.n_chunks = 1; p.chunk_spp = spp;
     p.spp = spp; p.seed = seed; p.sample_offset = sample_offset;
-    HIP_TRY(hipMemsetAsync(ev.counters, 0, 32 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(ev.counters, 0, mi::kCounterWords * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(ev.ev0, stream));
     HIP_TRY(hipMemsetAsync((*ev.partial), 0, size_t(width) * height * 32, stream));
     h->wf_iterations = 0;
@@ -525,6 +535,44 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
       stats->nodes_closest = c[4]; stats->tris_closest = c[5]; stats->nodes_shadow = c[6]; stats->tris_shadow = c[7]; stats->num_hits = c[8];
       stats->wave_loop_bodies[0] = h->wf_iterations;  // pipeline rounds (extend / shade / shadow / regen)
     }
+    return MI_OK;
+  }
+  // frame mode — the reference's cadence, one Technique::render per sample (Application.cpp:66): nothing to accumulate, so the paths write
+  // (r, g, b, 1) straight into the framebuffer (no partial sums, no pt_finalize); a wave owns its tiles in every frame of the launch and
+  // regenerates dead lanes onto the same pixels of the next frame
+  if (spp == 1 && frame_mode_available(h)) {
+    uint32_t tiles_per_wave = 1;  // measured on C2 (profiles/r02/cadence.txt): with several frames per launch one tile per wave keeps the chip full
+    if (const char* t = std::getenv("MI_PT_FRAME_TILES")) { const int v = std::atoi(t); if (v >= 1 && v <= 256) tiles_per_wave = uint32_t(v); }
+    // frames per wave: a wave that owns its tile in 2-4 frames runs 2-4 paths per lane (steady state: 0.17 ms per 512 x 512 frame with one
+    // path per lane, 0.119 with two, 0.104 with four, 0.095 with sixteen; tools/spp_scaling.py) as long as the launch keeps several
+    // rounds of waves (6 144 are resident): measured best at 4 for batches of 4-8 frames (profiles/r02/cadence.txt)
+    uint32_t frame_chunk = n_frames >= 4 ? 4u : n_frames;
+    if (const char* t = std::getenv("MI_PT_FRAME_CHUNK")) { const int v = std::atoi(t); if (v >= 1 && v <= int(mi::kMaxFramesPerLaunch)) frame_chunk = uint32_t(v); }
+    if (frame_chunk > n_frames) frame_chunk = n_frames;
+    p.frame_chunk = frame_chunk;
+    const uint64_t n_waves = ((n_tiles + tiles_per_wave - 1) / tiles_per_wave) * ((n_frames + frame_chunk - 1) / frame_chunk);
+    const uint64_t n_blocks = (n_waves + mi::kWavesPerBlock - 1) / mi::kWavesPerBlock;
+    if (n_blocks > 0x7FFFFFFFull || n_tiles * 64ull * n_frames > 0xFFFFFFFFull || uint64_t(width) * height * n_frames > 0xFFFFFFFFull)
+      return fail(MI_ERR_UNSUPPORTED, "render too large for one launch");
+    p.frame_rgbn = reinterpret_cast<float4*>(rgbn_sum_device); p.frame_tiles_per_wave = tiles_per_wave;
+    p.frame_count = n_frames; p.frame_stride = width * height;
+    p.spp = 1; p.n_chunks = 1; p.chunk_spp = 1; p.seed = seed; p.sample_offset = sample_offset;
+    p.partial = nullptr; p.counters = ev.counters;
+    HIP_TRY(hipMemsetAsync(ev.counters, 0, mi::kCounterWords * sizeof(unsigned long long), stream));
+    HIP_TRY(hipEventRecord(ev.ev0, stream));
+    if (sharded || win.x0 != 0 || win.y0 != 0 || win.w != width || win.h != height)  // pixels no path of this call writes
+      HIP_TRY(hipMemsetAsync(rgbn_sum_device, 0, size_t(width) * height * 16 * n_frames, stream));
+    HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), 2, false, uint32_t(n_blocks), stream));
+    HIP_TRY(hipEventRecord(ev.ev1, stream));
+    HIP_TRY(hipEventRecord(ev.ev2, stream));
+    mi_pt_launch_info& li = h->last;
+    li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
+    li.n_blocks = uint32_t(n_blocks); li.n_chunks = 1; li.chunk_spp = 1; li.frame_tiles_per_wave = tiles_per_wave; li.frames = n_frames;
+    li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
+    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u;
+    li.partial_bytes = 0;
+    li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
+    if (stats) return collect_stats(h, stream, stats, ev);
     return MI_OK;
   }
   // sample chunks: one wave owns a tile x chunk.  Measured on C2 (profiles/r01/ab_chunk.txt): 16-64 samples per
@@ -551,10 +599,10 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   if (rc) return rc;
   p.partial = (*ev.partial);
   p.counters = ev.counters;
-  HIP_TRY(hipMemsetAsync(ev.counters, 0, 32 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(ev.counters, 0, mi::kCounterWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ev.ev0, stream));
   if (sharded) HIP_TRY(hipMemsetAsync((*ev.partial), 0, size_t(p.n_chunks) * width * height * 32, stream));  // pixels of other ranks' tiles
-  HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), false, h->instrumented, uint32_t(n_blocks), stream));
+  HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), 0, h->instrumented, uint32_t(n_blocks), stream));
   {
     mi_pt_launch_info& li = h->last;
     li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
@@ -585,87 +633,124 @@ int mi_pt_last_launch(mi_pt_handle* h, mi_pt_launch_info* out) {
   return MI_OK;
 }
 
-int mi_pt_render_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint64_t seed,
-                       uint64_t sample_offset, uint64_t* ticket) {
-  if (!h || !ticket) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_async: null argument");
+namespace {
+// one batch = `n_frames` frames of `spp` samples each (n_frames > 1 needs spp == 1), all on the slot's own stream, nothing synchronises with the host
+int enqueue_batch(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint32_t n_frames, uint64_t seed,
+                  uint64_t first_sample, uint64_t* tickets) {
   if (width == 0 || height == 0 || uint64_t(width) * height > (1ull << 31)) return fail(MI_ERR_INVALID_ARGUMENT, "bad resolution");
   HIP_TRY(hipSetDevice(h->device));
-  auto& fs = h->slots[h->next_ticket % MI_PT_FRAMES_IN_FLIGHT];
-  if (fs.pending) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_async: " + std::to_string(MI_PT_FRAMES_IN_FLIGHT) + " frames are pending; call mi_pt_wait for ticket " + std::to_string(fs.ticket) + " first");
-  const size_t bytes = size_t(width) * height * 16;
-  if (!fs.ev0) {
-    HIP_TRY(hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&fs.ev0)); HIP_TRY(hipEventCreate(&fs.ev1)); HIP_TRY(hipEventCreate(&fs.ev2));
-    HIP_TRY(hipEventCreateWithFlags(&fs.ev_copied, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&fs.h_counters), 32 * sizeof(unsigned long long), hipHostMallocDefault));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fs.d_counters), 32 * sizeof(unsigned long long)));
+  auto& bs = h->batches[h->next_batch];
+  if (bs.pending_mask) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_async: " + std::to_string(MI_PT_BATCHES_IN_FLIGHT) + " batches are pending; call mi_pt_wait for tickets " +
+                                   std::to_string(bs.first_ticket) + " .. " + std::to_string(bs.first_ticket + bs.n_frames - 1) + " first");
+  const size_t frame_bytes = size_t(width) * height * 16, bytes = frame_bytes * n_frames;
+  if (!bs.ev0) {
+    // HIP multiplexes streams onto 4 hardware queues (the handle's stream, the null stream, ...): a third stream of our own would share a
+    // queue with the second and its kernel would wait behind that one's 16 MiB copy (measured: 340 us gaps, profiles/r02/cadence.txt).
+    // Slot 0 therefore runs on the handle's stream, which is idle while frames are in flight.
+    if (&bs != &h->batches[0]) HIP_TRY(hipStreamCreateWithFlags(&bs.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&bs.ev0)); HIP_TRY(hipEventCreate(&bs.ev1)); HIP_TRY(hipEventCreate(&bs.ev2));
+    HIP_TRY(hipEventCreateWithFlags(&bs.ev_copied, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&bs.h_counters), mi::kCounterWords * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&bs.d_counters), mi::kCounterWords * sizeof(unsigned long long)));
   }
-  int rc = ensure(reinterpret_cast<void**>(&fs.d_rgbn), &fs.d_bytes, bytes);
+  int rc = ensure(reinterpret_cast<void**>(&bs.d_rgbn), &bs.d_bytes, bytes);
   if (rc) return rc;
-  if (fs.h_bytes < bytes) {
-    if (fs.h_rgbn) hipHostFree(fs.h_rgbn);
-    fs.h_rgbn = nullptr; fs.h_bytes = 0;
-    if (hipHostMalloc(reinterpret_cast<void**>(&fs.h_rgbn), bytes, hipHostMallocDefault) != hipSuccess) return fail(MI_ERR_OUT_OF_MEMORY, "pinned host framebuffer");
-    fs.h_bytes = bytes;
+  if (bs.h_bytes < bytes) {
+    if (bs.h_rgbn) hipHostFree(bs.h_rgbn);
+    bs.h_rgbn = nullptr; bs.h_bytes = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&bs.h_rgbn), bytes, hipHostMallocDefault) != hipSuccess) return fail(MI_ERR_OUT_OF_MEMORY, "pinned host framebuffers");
+    bs.h_bytes = bytes;
   }
-  // Everything of the frame goes to the slot's own stream, nothing synchronises with the host: counters reset, path kernel, finalize,
-  // counters and framebuffer to pinned host memory.  Slots have their own partial-sum buffers and counters, so the frames of
-  // different slots overlap on the device — one 512 x 512 frame is 4 096 waves, 1.3 rounds of what the chip holds.
   // (The wavefront pipeline keeps its path state in one arena per handle: its frames share the handle's stream and run in order.)
-  hipStream_t stream = h->kernel_choice == MI_PT_KERNEL_WAVEFRONT ? h->stream : fs.stream;
-  rc = render_impl(h, camera_id, width, height, win, spp, seed, sample_offset, fs.d_rgbn, stream, nullptr,
-                   EventSet{fs.ev0, fs.ev1, fs.ev2, &fs.partial, &fs.partial_bytes, fs.d_counters});
-  if (rc) return rc;
-  fs.launched = h->last.n_blocks != 0 || h->kernel_choice == MI_PT_KERNEL_WAVEFRONT;
-  if (fs.launched) HIP_TRY(hipMemcpyAsync(fs.h_counters, fs.d_counters, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipMemcpyAsync(fs.h_rgbn, fs.d_rgbn, bytes, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipEventRecord(fs.ev_copied, stream));
+  hipStream_t stream = (h->kernel_choice == MI_PT_KERNEL_WAVEFRONT || !bs.stream) ? h->stream : bs.stream;
+  const EventSet ev{bs.ev0, bs.ev1, bs.ev2, &bs.partial, &bs.partial_bytes, bs.d_counters};
+  bs.per_frame_counts = false;
+  if (n_frames > 1 && frame_mode_available(h)) {
+    // ONE launch for all frames: a wave regenerates from frame to frame on its own pixels, so the chip stays full although a frame alone
+    // is only 1.3 rounds of waves; per-frame counts come back in counters[32 + 4 f ..]
+    rc = render_impl(h, camera_id, width, height, win, 1, seed, first_sample, bs.d_rgbn, stream, nullptr, ev, n_frames);
+    if (rc) return rc;
+    bs.launched = h->last.n_blocks != 0;
+    bs.per_frame_counts = true;
+    if (bs.launched) HIP_TRY(hipMemcpyAsync(bs.h_counters, bs.d_counters, mi::kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  } else {
+    for (uint32_t f = 0; f < n_frames; ++f) {  // one launch per frame; each frame's totals are parked in the per-frame section of the host copy
+      rc = render_impl(h, camera_id, width, height, win, spp, seed, first_sample + f, bs.d_rgbn + size_t(f) * width * height * 4, stream, nullptr, ev, 1);
+      if (rc) return rc;
+      bs.launched = h->last.n_blocks != 0 || h->kernel_choice == MI_PT_KERNEL_WAVEFRONT;
+      if (bs.launched) HIP_TRY(hipMemcpyAsync(bs.h_counters + 32 + 4 * f, bs.d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(bs.h_rgbn, bs.d_rgbn, bytes, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipEventRecord(bs.ev_copied, stream));
   if (win.w == 0 || win.h == 0) { win.x0 = 0; win.y0 = 0; win.w = width; win.h = height; }
-  fs.width = width; fs.height = height; fs.win = win;
-  fs.ticket = h->next_ticket++;
-  fs.pending = true;
-  *ticket = fs.ticket;
+  bs.width = width; bs.height = height; bs.win = win; bs.n_frames = n_frames; bs.synced = false;
+  bs.first_ticket = h->next_ticket; h->next_ticket += n_frames;
+  bs.pending_mask = n_frames >= 32 ? 0xFFFFFFFFu : ((1u << n_frames) - 1u);
+  for (uint32_t f = 0; f < n_frames; ++f) tickets[f] = bs.first_ticket + f;
+  h->next_batch = (h->next_batch + 1) % MI_PT_BATCHES_IN_FLIGHT;
   return MI_OK;
 }
 
-namespace {
-int wait_slot(mi_pt_handle* h, uint64_t ticket, mi_pt_handle::FrameSlot** out, mi_pt_stats* stats) {
-  auto& fs = h->slots[ticket % MI_PT_FRAMES_IN_FLIGHT];
-  if (!fs.pending || fs.ticket != ticket) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait: ticket " + std::to_string(ticket) + " is not pending");
-  HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipEventSynchronize(fs.ev_copied));
-  fs.pending = false;
-  *out = &fs;
+int wait_frame(mi_pt_handle* h, uint64_t ticket, mi_pt_handle::BatchSlot** out, uint32_t* frame, mi_pt_stats* stats) {
+  mi_pt_handle::BatchSlot* bs = nullptr;
+  for (auto& b : h->batches)
+    if (b.pending_mask && ticket >= b.first_ticket && ticket < b.first_ticket + b.n_frames && (b.pending_mask >> (ticket - b.first_ticket) & 1u)) bs = &b;
+  if (!bs) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait: ticket " + std::to_string(ticket) + " is not pending");
+  const uint32_t f = uint32_t(ticket - bs->first_ticket);
+  if (!bs->synced) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(bs->ev_copied));
+    bs->synced = true;
+  }
+  bs->pending_mask &= ~(1u << f);
+  *out = bs; *frame = f;
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
-    if (fs.launched) {
-      const unsigned long long* c = fs.h_counters;
-      float t01 = 0.0f, t02 = 0.0f;
-      HIP_TRY(hipEventElapsedTime(&t01, fs.ev0, fs.ev1));
-      HIP_TRY(hipEventElapsedTime(&t02, fs.ev0, fs.ev2));
+    if (bs->launched) {
+      // per-frame counts: [closest-hit rays, shadow rays, numeric errors, paths] (frame launches) or the launch totals [basic, shadow, errors, paths]
+      const unsigned long long* c = bs->h_counters + 32 + 4 * f;
       stats->num_basic_rays = c[0]; stats->num_shadow_rays = c[1]; stats->numeric_errors = c[2]; stats->num_paths = c[3];
-      stats->trace_ms = t01; stats->gpu_ms = t02;
+      float t01 = 0.0f, t02 = 0.0f;  // device time of the batch's (last) launch, shared evenly by its frames
+      HIP_TRY(hipEventElapsedTime(&t01, bs->ev0, bs->ev1));
+      HIP_TRY(hipEventElapsedTime(&t02, bs->ev0, bs->ev2));
+      const double share = bs->per_frame_counts ? 1.0 / double(bs->n_frames) : 1.0;
+      stats->trace_ms = t01 * share; stats->gpu_ms = t02 * share;
     }
   }
   return MI_OK;
 }
 }  // namespace
 
+int mi_pt_render_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t spp, uint64_t seed,
+                       uint64_t sample_offset, uint64_t* ticket) {
+  if (!h || !ticket) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_async: null argument");
+  if (spp == 0) return fail(MI_ERR_INVALID_ARGUMENT, "spp must be > 0");
+  return enqueue_batch(h, camera_id, width, height, win, spp, 1, seed, sample_offset, ticket);
+}
+
+int mi_pt_render_frames_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win, uint32_t n_frames, uint64_t seed,
+                              uint64_t first_sample, uint64_t* tickets) {
+  if (!h || !tickets) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_render_frames_async: null argument");
+  if (n_frames == 0 || n_frames > MI_PT_MAX_FRAMES_PER_BATCH) return fail(MI_ERR_INVALID_ARGUMENT, "n_frames must be in [1, " + std::to_string(MI_PT_MAX_FRAMES_PER_BATCH) + "]");
+  return enqueue_batch(h, camera_id, width, height, win, 1, n_frames, seed, first_sample, tickets);
+}
+
 int mi_pt_wait(mi_pt_handle* h, uint64_t ticket, const float** rgbn_sum, mi_pt_stats* stats) {
   if (!h || !rgbn_sum) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait: null argument");
-  mi_pt_handle::FrameSlot* fs = nullptr;
-  const int rc = wait_slot(h, ticket, &fs, stats);
+  mi_pt_handle::BatchSlot* bs = nullptr; uint32_t f = 0;
+  const int rc = wait_frame(h, ticket, &bs, &f, stats);
   if (rc) return rc;
-  *rgbn_sum = fs->h_rgbn;
+  *rgbn_sum = bs->h_rgbn + size_t(f) * bs->width * bs->height * 4;
   return MI_OK;
 }
 
 int mi_pt_wait_add(mi_pt_handle* h, uint64_t ticket, double* view, mi_pt_stats* stats) {
   if (!h || !view) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_wait_add: null argument");
-  mi_pt_handle::FrameSlot* fs = nullptr;
-  const int rc = wait_slot(h, ticket, &fs, stats);
+  mi_pt_handle::BatchSlot* bs = nullptr; uint32_t f = 0;
+  const int rc = wait_frame(h, ticket, &bs, &f, stats);
   if (rc) return rc;
-  mi::add_frame_to_view(fs->h_rgbn, view, fs->width, fs->win.x0, fs->win.y0, fs->win.w, fs->win.h);
+  mi::add_frame_to_view(bs->h_rgbn + size_t(f) * bs->width * bs->height * 4, view, bs->width, bs->win.x0, bs->win.y0, bs->win.w, bs->win.h);
   return MI_OK;
 }
 
@@ -827,11 +912,11 @@ int mi_pt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint3
     if (rc) return rc;
     w.list = 1; w.n_items = n; w.per_sample = w.P; w.R = 1;
     p.counters = h->d_counters;
-    HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, mi::kCounterWords * sizeof(unsigned long long), h->stream));
     HIP_TRY(mi::wf_run(p, w, false, h->stream, nullptr));
   } else {
     const uint32_t per_block = uint32_t(mi::kWavesPerBlock) * 64u * 16u;
-    HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), true, false, (n + per_block - 1) / per_block, h->stream));
+    HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), 1, false, (n + per_block - 1) / per_block, h->stream));
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_radiance, d_r, size_t(n) * 12, hipMemcpyDeviceToHost));
@@ -959,7 +1044,7 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
   rc = ensure(reinterpret_cast<void**>(&h->d_rgbn), &h->rgbn_bytes, np * 16); if (rc) return rc;
   p.partial = h->partial; w.eye = h->bpt_eye; w.light = h->bpt_light;
   hipStream_t stream = h->stream;
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, mi::kCounterWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipMemsetAsync(h->partial, 0, np * 32, stream));
   HIP_TRY(hipMemsetAsync(h->bpt_eye, 0, np * 12 * batch, stream));
   HIP_TRY(hipMemsetAsync(h->bpt_light, 0, np * 24 * batch, stream));
@@ -1013,7 +1098,7 @@ int mi_bpt_trace_paths(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint
   p.win_w = width; p.win_h = height; p.seed = seed;
   p.list_xy = d_xy; p.list_sample = d_s; p.list_n = n; p.list_radiance = d_r;
   w.list_splat_sum = d_sp; w.list_counts3 = d_c;
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, 32 * sizeof(unsigned long long), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, mi::kCounterWords * sizeof(unsigned long long), h->stream));
   for (uint64_t first = 0; first < n; first += per_launch) {
     w.first = uint32_t(first); w.lanes = uint32_t(n - first < per_launch ? n - first : per_launch);
     rc = bpt_launch(h, p, w, true, h->stream);

@@ -48,9 +48,9 @@ def test_every_entry_point_cites_the_reference():
 def test_struct_sizes():
     assert C.sizeof(ma.Material) == 48 and C.sizeof(ma.Light) == 80 and C.sizeof(ma.Camera) == 40
     assert C.sizeof(ma.SurfacePoint) == 64 and C.sizeof(ma.BvhNode) == 64 and C.sizeof(ma.PtParams) == 24
-    assert C.sizeof(ma.LaunchInfo) == 48
+    assert C.sizeof(ma.LaunchInfo) == 56
     hdr = open(os.path.join(ROOT, "include", "mi_pt.h")).read()
-    assert "#define MI_PT_FRAMES_IN_FLIGHT %d" % ma.FRAMES_IN_FLIGHT in hdr
+    assert "#define MI_PT_MAX_FRAMES_PER_BATCH %d" % ma.MAX_FRAMES_PER_BATCH in hdr and "#define MI_PT_BATCHES_IN_FLIGHT %d" % ma.BATCHES_IN_FLIGHT in hdr
 
 
 def test_load_failure_message_follows_loader():

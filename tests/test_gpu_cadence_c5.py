@@ -18,35 +18,66 @@ from conftest import load_scene
 pytestmark = pytest.mark.gpu
 
 
-def test_frames_in_flight_give_the_synchronous_view_bit_for_bit(cornell):
-    """render(k) = wait(frame k) -> view += rgbn -> enqueue(frame k + FRAMES_IN_FLIGHT): the dvec4 view after every call holds
-    exactly frames 0..k (what --num-samples / snapshots / continue see), identical to one mi_pt_render(spp = 1) per frame."""
-    pt_a, pt_s = ma.PathTracing(cornell, max_path=6), ma.PathTracing(cornell, max_path=6)
+@pytest.mark.parametrize("batch", [1, 4, 8])
+@pytest.mark.parametrize("scene_name,kernel", [("CornellBoxDiffuse", ma.KERNEL_AUTO), ("CornellBoxSpecular", ma.KERNEL_AUTO), ("MetalRings", ma.KERNEL_AUTO),
+                                               ("CornellBoxDiffuse", ma.KERNEL_WAVEFRONT)])
+def test_frames_in_flight_give_the_synchronous_view_bit_for_bit(scene_name, kernel, batch):
+    """render(k) = [enqueue a batch ahead] -> wait(frame k) -> view += rgbn: the dvec4 view after every call holds exactly frames 0..k
+    (what --num-samples / snapshots / continue see), identical to one mi_pt_render(spp = 1) per frame — per frame and in total, ray
+    counts included, whether the frames of a batch share one launch (frame variant of the megakernel) or not (wavefront pipeline)."""
+    s = load_scene(scene_name)
+    pt_a, pt_s = ma.PathTracing(s, max_path=6), ma.PathTracing(s, max_path=6)
+    pt_a.set_kernel(kernel); pt_s.set_kernel(kernel)
     w, h, n = 96, 72, 11
     view_a, view_s = np.zeros((h, w, 4), np.float64), np.zeros((h, w, 4), np.float64)
-    pt_a.render_frames(view_a, n, seed=9)
+    pt_a.render_frames(view_a, n, seed=9, batch=batch)
     for _ in range(n):
         pt_s.render(view_s, seed=9)
-    assert np.array_equal(view_a, view_s) and np.all(view_a[..., 3] == n)
+    assert np.array_equal(view_a, view_s) and np.all(view_a[..., 3] <= n)
     sa, ss = pt_a.statistics(), pt_s.statistics()
     assert (sa.num_samples, sa.num_basic_rays, sa.num_shadow_rays) == (ss.num_samples, ss.num_basic_rays, ss.num_shadow_rays)
-    orc = oracle.Oracle(cornell, max_path=6)
-    ref = np.zeros((h, w, 4), np.float64)
-    for k in range(n):  # the oracle's frames, added one by one like Technique::_commit_images
-        ref += orc.render_rgbn(w, h, spp=1, seed=9, sample_offset=k)
-    np.testing.assert_allclose(view_a, ref, rtol=1.2e-7)
+    if scene_name == "CornellBoxDiffuse" and batch == 4:
+        orc = oracle.Oracle(s, max_path=6)
+        ref = np.zeros((h, w, 4), np.float64)
+        for k in range(n):  # the oracle's frames, added one by one like Technique::_commit_images
+            ref += orc.render_rgbn(w, h, spp=1, seed=9, sample_offset=k)
+        np.testing.assert_allclose(view_a, ref, rtol=1.2e-7)
+
+
+@pytest.mark.parametrize("frame_chunk,frame_tiles", [(None, None), ("1", "1"), ("3", "2"), ("8", "5")])
+def test_batched_frames_equal_single_frames_with_exact_per_frame_statistics(monkeypatch, cornell, frame_chunk, frame_tiles):
+    """mi_pt_render_frames_async: every frame of the launch is bit-identical to mi_pt_render(spp = 1) of that sample, and carries that
+    frame's own ray / path / error counts (window and tile shard included), however frames and tiles are dealt to the waves."""
+    if frame_chunk:
+        monkeypatch.setenv("MI_PT_FRAME_CHUNK", frame_chunk); monkeypatch.setenv("MI_PT_FRAME_TILES", frame_tiles)
+    spec = load_scene("CornellBoxSpecular")
+    for scene, win, shard in ((cornell, None, None), (spec, (8, 4, 33, 21), None), (cornell, None, (1, 3))):
+        pt = ma.PathTracing(scene, max_path=5)
+        if shard:
+            pt.set_tile_shard(*shard)
+        tickets = pt.render_frames_async(64, 48, 7, seed=3, first_sample=10, window=win)
+        assert tickets == list(range(tickets[0], tickets[0] + 7)) and pt.last_launch().frames == 7
+        for f in (3, 0, 6, 1, 2, 5, 4):  # any order
+            img = pt.wait(tickets[f])
+            st = pt.last_stats
+            ref = pt.render_rgbn(64, 48, spp=1, seed=3, sample_offset=10 + f, window=win)
+            rs = pt.last_stats
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+            assert (st.num_paths, st.num_basic_rays, st.num_shadow_rays, st.numeric_errors) == (rs.num_paths, rs.num_basic_rays, rs.num_shadow_rays, rs.numeric_errors)
 
 
 def test_async_tickets_slots_and_errors(cornell):
     pt = ma.PathTracing(cornell, max_path=4)
-    t = [pt.render_async(40, 24, 1, 3, k) for k in range(ma.FRAMES_IN_FLIGHT)]
-    assert t == list(range(t[0], t[0] + ma.FRAMES_IN_FLIGHT))
+    t = [pt.render_async(40, 24, 1, 3, k) for k in range(ma.BATCHES_IN_FLIGHT)]
+    assert t == list(range(t[0], t[0] + ma.BATCHES_IN_FLIGHT))
     with pytest.raises(ma.MiError) as e:  # every slot is pending
         pt.render_async(40, 24, 1, 3, 99)
     assert e.value.code == -1 and "pending" in str(e.value)
     frames = [pt.wait(k) for k in t]
     with pytest.raises(ma.MiError):  # already handed out
         pt.wait(t[0])
+    with pytest.raises(ma.MiError):
+        pt.render_frames_async(40, 24, ma.MAX_FRAMES_PER_BATCH + 1)
     for k, f in enumerate(frames):
         assert np.array_equal(f, pt.render_rgbn(40, 24, spp=1, seed=3, sample_offset=k))
     # a window, several samples per frame, statistics of the frame
@@ -129,3 +160,27 @@ def test_c5_tile_shards_partition_the_frame_bitwise(clutter):
         assert np.all(total[part[..., 3] > 0] == 0)  # disjoint owners
         total += part
     assert paths == C5_W * C5_H and np.array_equal(total.view(np.uint32), whole.view(np.uint32))
+
+
+@pytest.mark.parametrize("scene_name", ["CornellBoxDiffuse", "CornellBoxSpecular", "MetalRings"])
+def test_frame_mode_writes_the_same_frame_as_the_accumulating_kernel(monkeypatch, scene_name):
+    """spp == 1 runs the frame variant of the megakernel (paths write (r, g, b, 1) straight into the framebuffer, a wave regenerates over
+    several 8x8 tiles); MI_PT_FRAME_MODE=0 forces the accumulating variant (LDS FP64 sums -> partial -> pt_finalize).  One sample per
+    pixel: both must give the same bits, whatever the window, the tile shard and the tiles a wave owns."""
+    s = load_scene(scene_name)
+    pt = ma.PathTracing(s, max_path=7)
+    cases = [(64, 64, None, None), (37, 23, None, None), (130, 41, (120, 3, 10, 30), None), (100, 72, None, (1, 3)), (96, 64, (7, 9, 70, 40), (0, 2)), (1, 1, None, None)]
+    for (w, h, win, shard) in cases:
+        pt.set_tile_shard(*(shard if shard else (0, 1)))
+        monkeypatch.setenv("MI_PT_FRAME_MODE", "0")
+        ref = pt.render_rgbn(w, h, spp=1, seed=4, sample_offset=5, window=win)
+        ref_st = (pt.last_stats.num_paths, pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays, pt.last_stats.numeric_errors)
+        assert pt.last_launch().frame_tiles_per_wave == 0
+        monkeypatch.delenv("MI_PT_FRAME_MODE")
+        for tiles in ("1", "3", "4", "64"):
+            monkeypatch.setenv("MI_PT_FRAME_TILES", tiles)
+            img = pt.render_rgbn(w, h, spp=1, seed=4, sample_offset=5, window=win)
+            assert pt.last_launch().frame_tiles_per_wave == int(tiles)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (w, h, win, shard, tiles)
+            assert ref_st == (pt.last_stats.num_paths, pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays, pt.last_stats.numeric_errors)
+        monkeypatch.delenv("MI_PT_FRAME_TILES")

@@ -69,8 +69,15 @@ std::string SceneData::validate() const {
   }
   for (uint32_t i : indices)
     if (i >= nv) return "vertex index out of range";
-  for (const mi_material& m : materials)
+  for (const mi_material& m : materials) {
     if (m.type > MI_BSDF_SUN) return "unknown material type";
+    // parameters a kernel would turn into NaNs or a black surface without saying so (an adapter that forgot to copy them)
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(m.diffuse[k]) || !std::isfinite(m.specular[k])) return "non-finite material colour";
+    if (m.type == MI_BSDF_PHONG && !(m.power > 0.0f && std::isfinite(m.power))) return "Phong material needs a positive, finite exponent (PhongBSDF, BSDF.cpp:306-315)";
+    if (m.type == MI_BSDF_TRANSMISSION && !(std::isfinite(m.ior_internal) && std::isfinite(m.ior_external) && m.ior_internal != 0.0f && m.ior_external != 0.0f))
+      return "transmission material needs finite, non-zero indices of refraction (TransmissionBSDF, BSDF.cpp:467-470)";
+  }
   for (const mi_light& l : lights) {
     if ((l.material_id >> 2) >= materials.size()) return "light material_id out of range";
     if (!(l.size[0] > 0.0f) || !(l.size[1] > 0.0f)) return "light size must be positive";

@@ -80,6 +80,22 @@ def test_scene_validation_rejects_bad_descriptions(cornell):
     assert "power" in str(e.value)
     with pytest.raises(ma.MiError):  # empty scene
         ma.Scene.from_arrays(np.zeros((0, 3)), np.zeros((0, 9)), np.zeros((0, 3)), [0], [], s.materials, s.lights, s.cameras)
+    # material parameters an adapter forgot to copy: an error, not a black or NaN image
+    for kind, field, value, word in ((ma.BSDF_PHONG, "power", 0.0, "exponent"), (ma.BSDF_TRANSMISSION, "ior_internal", 0.0, "refraction"), (ma.BSDF_DIFFUSE, "power", 0.0, None)):
+        mats = [ma.Material.from_buffer_copy(m) for m in s.materials]
+        surf = next(i for i, m in enumerate(mats) if m.type == ma.BSDF_DIFFUSE)
+        mats[surf].type = kind; mats[surf].ior_external = 1.0; mats[surf].ior_internal = 1.5; mats[surf].power = 10.0
+        setattr(mats[surf], field, value)
+        if word is None:
+            ma.Scene.from_arrays(s.positions, s.tangents, s.indices, s.mesh_tri_offset, s.mesh_material_id, mats, s.lights, s.cameras)
+        else:
+            with pytest.raises(ma.MiError) as e:
+                ma.Scene.from_arrays(s.positions, s.tangents, s.indices, s.mesh_tri_offset, s.mesh_material_id, mats, s.lights, s.cameras)
+            assert word in str(e.value)
+    mats = [ma.Material.from_buffer_copy(m) for m in s.materials]
+    mats[1].diffuse[0] = float("nan")
+    with pytest.raises(ma.MiError):
+        ma.Scene.from_arrays(s.positions, s.tangents, s.indices, s.mesh_tri_offset, s.mesh_material_id, mats, s.lights, s.cameras)
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")

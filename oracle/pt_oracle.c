@@ -26,12 +26,19 @@
  *   Tie-breaking between equal-t hits is not pinned by Embree; this restatement (and the
  *   GPU path) define it as: smaller t wins, equal t -> smaller global triangle index wins.
  *
- * Parity status: the reference executable cannot be built in this image (glm, Embree 2,
- * OpenEXR, the assimp fork are absent and may not be stood in for).  The oracle is pinned by
- * (1) the reference's own camera test vectors (unit_tests/Cameras.test.cpp:22-44,
- * Cameras.cpp:164-189, Technique.cpp:118-152) and (2) closed-form results of the estimator it
- * restates (white furnace, analytic rectangle-light irradiance) — see tests/test_oracle_*.py.
- * Everything that depends on Embree tie-breaks or on the assimp fork is "parity unpinned".
+ * Parity status: PARITY UNPINNED for the hot path.  The reference executable cannot be built in
+ * this image (glm, Embree 2, OpenEXR, the assimp fork are absent and may not be stood in for) and
+ * the reference holds no executable test, golden vector or image for PT.  What the reference DOES
+ * hold pins only the cameras: unit_tests/Cameras.test.cpp:22-44, the inline unittest blocks of
+ * Cameras.cpp:164-189, Technique.cpp:118-152, main.cpp:24-56 and unittest.cpp:177-182
+ * (tests/test_camera.py, tests/test_oracle_kat.py, tests/golden/reference_constants.json).
+ * Everything else — _traceEye / _connect, the BSDFs, light sampling, intersect / occluded — is
+ * checked against closed-form results of the estimator it restates (white furnace, analytic
+ * rectangle-light irradiance, sampling densities) and by line-by-line citation, not against
+ * reference outputs.  unit_test.py's constant 0.01 is a scheduling heuristic of a stale script
+ * (see reference_constants.json), not a value to meet: the absolute radiometric scale of the
+ * importer, Embree's tie-breaks and the assimp fork's conventions are unpinned.
+ * What IS exact: the GPU path equals this restatement bit for bit.
  *
  * Random numbers: the reference PT cannot be seeded (Options.cpp:821-833; every tile reseeds
  * from std::random_device, Technique.cpp:170-174), so streams are defined here, not copied:
@@ -226,6 +233,9 @@ static inline float mi_powf(float x, float y) {
 }
 
 ORC_API void orc_powf(uint32_t n, const float* x, const float* y, float* out) { for (uint32_t i = 0; i < n; ++i) out[i] = mi_powf(x[i], y[i]); }
+/* the build's own sin / cos (argument in turns) and asin, exposed so tests can hold them against the reference's start-up assertions (main.cpp:24-39) */
+ORC_API void orc_sincos_2pi(float u, float* s, float* c) { sincos_2pi(u, s, c); }
+ORC_API float orc_asinf(float x) { return mi_asinf(x); }
 
 /* ------------------------------------------------------------------ RNG (defined here) */
 typedef struct { uint64_t state; } rng_t;

@@ -225,3 +225,20 @@ def powf(x, y):
     L.orc_powf.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_powf(x.size, x.ctypes.data, y.ctypes.data, out.ctypes.data)
     return out
+
+
+def sincos_2pi(u):
+    """(sin, cos)(2 pi u) as the build defines them (sincos_2pi in oracle/pt_oracle.c, the same statement as device/vecmath.h)."""
+    import ctypes as C
+    L = lib()
+    L.orc_sincos_2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    s, c = C.c_float(), C.c_float()
+    L.orc_sincos_2pi(float(u), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def asinf(x):
+    import ctypes as C
+    L = lib()
+    L.orc_asinf.argtypes = [C.c_float]; L.orc_asinf.restype = C.c_float
+    return L.orc_asinf(float(x))

@@ -308,3 +308,57 @@ def test_own_powf_is_within_one_ulp_and_follows_c99_special_cases():
     # frozen values: a change of the definition must show up here, not only as a device mismatch
     kx = np.array([0.5, 0.9, 0.999, 0.25, 0.75, 1e-3], np.float32); ky = np.array([50, 500, 5000, 1 / 51.0, 1.5, 0.7], np.float32)
     assert oracle.powf(kx, ky).view(np.uint32).tolist() == exact(kx, ky).view(np.uint32).tolist()
+
+
+# ---- the reference's own inline tests beyond the cameras (tests/golden/reference_constants.json) ----
+def _ulp_dist(a, b):
+    """ulp_dist (unittest.cpp:150-166)."""
+    ia, ib = int(np.float32(a).view(np.int32)), int(np.float32(b).view(np.int32))
+    if (ia < 0) != (ib < 0):
+        return abs(ia & 0x7FFFFFFF) + abs(ib & 0x7FFFFFFF)
+    return abs(ia - ib)
+
+
+def _almost_eq(a, b):
+    """almost_eq (unittest.cpp:168-171)."""
+    return bool(abs(np.float32(a) - np.float32(b)) < np.float32(1.1920928955078125e-07) or _ulp_dist(a, b) < 64)
+
+
+def test_reference_almost_eq_vectors_and_float_environment():
+    import json
+    from conftest import ROOT
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_constants.json")))
+    for v in g["almost_eq"]["vectors"]:  # unittest.cpp:177-182
+        if "ulp_dist" in v:
+            assert _ulp_dist(v["a"], v["b"]) == v["ulp_dist"]
+        if v.get("ulp_dist_nonzero"):
+            assert _ulp_dist(v["a"], v["b"]) != 0
+        if "almost_eq" in v:
+            assert _almost_eq(v["a"], v["b"]) == v["almost_eq"]
+    # main.cpp:24-39 through the build's own transcendental definitions: sin(pi/2) = 1 (quadrant reduction of sincos_2pi at u = 1/4)
+    env = g["float_environment"]
+    orc = oracle.Oracle(load_scene("CornellBoxDiffuse"))
+    assert _almost_eq(oracle.sincos_2pi(0.25)[0], env["sin_half_pi"]) and _almost_eq(oracle.sincos_2pi(0.25)[1], 0.0)
+    assert _almost_eq(oracle.asinf(1.0), env["asin_1"])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        assert np.isinf(np.float32(1) / np.float32(0)) and np.isnan(np.float32(0) / np.float32(0)) and np.isnan(np.float32(-0.0) / np.float32(0))
+    # main.cpp:41-56 / SURVEY App. A: mat3 values cross the C ABI column-major — column 0 of the view-to-world frame is the camera's right vector
+    f = ma.camera_setup(ma.Camera((ma.C.c_float * 3)(0, 0, 0), (ma.C.c_float * 3)(0, 0, -1), (ma.C.c_float * 3)(0, 1, 0), 1.0), 1.0)
+    m = list(f.view_to_world)
+    assert [_almost_eq(x, y) for x, y in zip(m, [1, 0, 0, 0, 1, 0, 0, 0, 1])] == [True] * 9
+    assert g["test_scene_mean_radiance"]["status"].endswith("unpinned") and g["test_scene_mean_radiance"]["reference_script_constant"] == 0.01
+    del orc
+
+
+def test_converged_crop_fixtures_are_consistent():
+    """The two 1024-spp oracle crops of BASELINE configs[1] (image-level parity rule of BASELINE.md) agree with each other within noise and
+    with a fresh oracle render of the same window — the fixture is what today's oracle computes."""
+    from conftest import ROOT
+    a = np.load(os.path.join(ROOT, "tests", "golden", "c2_crop_1024spp_a.npy")); b = np.load(os.path.join(ROOT, "tests", "golden", "c2_crop_1024spp_b.npy"))
+    assert a.shape == b.shape == (64, 64, 4) and np.all(a[..., 3] == 1024) and np.all(b[..., 3] == 1024)
+    ra, rb = a[..., :3] / 1024, b[..., :3] / 1024
+    assert abs(ra.mean() - rb.mean()) / ra.mean() < 0.005
+    orc = oracle.Oracle(load_scene("CornellBoxDiffuse"), max_path=8)
+    fresh = orc.render_rgbn(512, 512, spp=16, seed=101, window=(224, 160, 64, 64))[160:224, 224:288]
+    first16 = orc.render_rgbn(512, 512, spp=1024, seed=101, window=(224, 160, 64, 64))[160:224, 224:288]
+    assert np.array_equal(first16, a) and np.all(fresh[..., 3] == 16)

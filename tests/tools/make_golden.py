@@ -14,6 +14,7 @@ import master_amd as ma  # noqa: E402
 import oracle  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
+C2_CROP = (224, 160, 64, 64)  # x0, y0, w, h: floor, both boxes' edges and their shadows
 os.makedirs(G, exist_ok=True)
 
 
@@ -26,8 +27,27 @@ def main():
         "round_trip": {"resolution": [800.0, 600.0], "fov_y": 1.5707963267948966, "position": [123.4, 345.0], "from": "Cameras.cpp:164-173"},
         "centre_ray_800x600": {"direction": [0.0, 0.0, -1.0], "from": "unit_tests/Cameras.test.cpp:40"},
         "corner_ray_aspect1": {"direction": [-0.577, -0.577, -0.577], "tol": 1e-3, "from": "unit_tests/Cameras.test.cpp:47"},
-        "test_scene_mean_radiance": {"value": 1.0, "scenes": ["TestCase0", "TestCase2", "TestCase5", "TestCase25", "TestCaseFurnace"],
-                                     "from": "models/TestCase*.blend are normalised by their author so the 512x512 image averages 1 (lamp energies such as 53.9002 are tuned); unit_test.py:77-83 ranks renders by distance of the average from a constant"},
+        # NOT a pin of the absolute scale.  What the reference holds: unit_test.py:77-83 orders TestCase renders by the squared distance of
+        # their image average from `expected = [0.01] * 3` to decide which one gets the next 20 minutes; it asserts nothing.  The script is
+        # stale against the tree next to it: it runs `master avg`, an action parseAction (Options.cpp:396-409) does not know ("average" is),
+        # and parses the output with float() although main.cpp:81-82 prints "[x y z]".  Through this build's .blend reader the models average
+        # 1.000 +- 0.003 — 100 x the script's constant — which says the author normalised them to SOME constant (lamp energies such as
+        # 53.9002 are tuned) and that the script's constant belongs to another normalisation or unit than today's loader.cpp:434-456
+        # (exitance = lamp rgb * energy, radiance = exitance / pi).  Neither value can be confirmed without running the reference:
+        # the absolute radiometric scale of the importer is UNPINNED.  The tests use 1.0 as a self-consistency check of reader + estimator.
+        "test_scene_mean_radiance": {"value": 1.0, "status": "self-consistency value of this build, absolute scale unpinned",
+                                     "reference_script_constant": 0.01, "reference_script": "unit_test.py:77-83 (scheduling heuristic of a stale script, not an assertion)",
+                                     "scenes": ["TestCase0", "TestCase2", "TestCase5", "TestCase25", "TestCaseFurnace"]},
+        # the comparison the reference's inline unittest blocks use (unittest.cpp:150-175) and its own vectors (unittest.cpp:177-182)
+        "almost_eq": {"definition": "abs(a - b) < FLT_EPSILON || ulp_dist(a, b) < 64; ulp_dist = |int(a) - int(b)| for equal signs, sum of magnitudes otherwise",
+                      "from": "unittest.cpp:150-175", "flt_epsilon": 1.1920928955078125e-07, "ulps": 64,
+                      "vectors": [{"a": 0.0, "b": -0.0, "ulp_dist": 0, "from": "unittest.cpp:178"},
+                                  {"a": 1.0000001, "b": 1.0000002, "ulp_dist_nonzero": True, "from": "unittest.cpp:179"},
+                                  {"a": 1.0, "b": -1.0, "almost_eq": False, "from": "unittest.cpp:180"},
+                                  {"a": 1.0, "b": 1.0, "almost_eq": True, "from": "unittest.cpp:181"}]},
+        # floating-point environment the reference asserts at start-up (main.cpp:24-39) and glm conventions (main.cpp:41-56)
+        "float_environment": {"sin_half_pi": 1.0, "asin_1": 1.5707963267948966, "inf": "1/0", "nan": ["0/0", "-0/0"], "from": "main.cpp:24-39"},
+        "mat4_conventions": {"default_is_identity": True, "indexing": "column major: m[0] = (1, 1, 0, 0) makes m * (1, 1, 1, 1) = (1, 2, 1, 1)", "from": "main.cpp:41-56"},
     }, open(os.path.join(G, "reference_constants.json"), "w"), indent=1)
 
     # (b) oracle regression pins
@@ -50,6 +70,13 @@ def main():
     nodes, order, morton = oracle.Oracle(s).bvh()
     json.dump({"source": "oracle regression pin: LBVH of CornellBoxDiffuse", "sorted_tri": order.tolist(), "morton": morton.tolist(),
                "links": [[int(n["link0"]), int(n["link1"])] for n in nodes]}, open(os.path.join(G, "cornell_lbvh_pin.json"), "w"), indent=1)
+    # (c) converged crops of BASELINE configs[1] by the oracle, for the image-level parity rule of BASELINE.md (RMSE(GPU, CPU) <= 1.5 x
+    # RMSE(CPU, CPU') and mean-radiance bias < 0.5 %): a 64 x 64 window of the 512 x 512 frame at 1024 spp, two independent seeds
+    for tag, seed in (("a", 101), ("b", 202)):
+        o = oracle.Oracle(s, max_path=8)
+        img = o.render_rgbn(512, 512, spp=1024, seed=seed, window=C2_CROP)
+        x0, y0, w, h = C2_CROP
+        np.save(os.path.join(G, "c2_crop_1024spp_%s.npy" % tag), img[y0:y0 + h, x0:x0 + w])
     print("golden written to", G)
 
 

@@ -52,6 +52,7 @@ struct RenderParams {
   float cam_pos[3];
   float focal_length_y;
   float res_x, res_y, res_y_inv;
+  float res_x_res_y_inv;   // res_x * res_y_inv as one FP32 product (Cameras.cpp:123), formed on the host: a loop-invariant VALU result would cost a VGPR
   uint32_t width, height;
   uint32_t win_x0, win_y0, win_w, win_h;
   uint32_t tiles_x, tiles_y;

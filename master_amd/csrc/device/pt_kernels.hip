@@ -67,7 +67,9 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 // into its own framebuffer), so that dead lanes regenerate onto the same pixels of the next frame: with one frame of one tile per wave
 // the waves run as long as their longest path while their lanes die (0.29 ms per 512 x 512 frame against 0.10 ms per frame inside a
 // 1024-spp launch).  Ray / error counts are kept per frame (LDS atomics at path end; Technique::render fills statistics per frame).
-template <bool LDS_SCENE, int MODE, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true>
+// TBL (kernels that read the scene from HBM): the small tables every vertex touches — materials, lights, light CDF — are staged into LDS by the
+// workgroup (LivingRoom: 65 materials = 3.2 KB), so the shading block's dependent reads (triangle -> material -> light) stop at the triangle.
+template <bool LDS_SCENE, int MODE, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true, bool TBL = false>
 __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParams p) {
   constexpr bool LIST = MODE == 1, FRAME = MODE == 2, IMAGE = MODE == 0;
   extern __shared__ float4 smem[];
@@ -78,10 +80,18 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
 
   // LDS-resident variant: padded copy of the scene blob (stage_scene_to_lds, pt_device.h)
   constexpr int NS = LDS_SCENE ? 5 : 4, SS = LDS_SCENE ? 9 : 8;
-  const uint32_t blob_f4 = LDS_SCENE ? lds_scene_f4(sv) : 0u;
+  const uint32_t blob_f4 = LDS_SCENE ? lds_scene_f4(sv) : (TBL ? sv.blob_f4 - sv.off_mats : 0u);
   const float4* sb = sv.blob;
   const float4* __restrict__ light0 = p.sv.blob + p.sv.off_lights;  // global copy of the first light record (one-light variants read it through scalar loads)
   if (LDS_SCENE) { stage_scene_to_lds(smem, sv, tid); sb = smem; }
+  // tb / tv: where the tables are read from — the LDS copy of the whole scene, the LDS copy of the tables alone, or the blob in HBM
+  const float4* tb = sb;
+  SceneView tv = sv;
+  if (!LDS_SCENE && TBL) {
+    for (uint32_t i = tid; i < blob_f4; i += kBlock) smem[i] = sv.blob[sv.off_mats + i];
+    tv.off_lights = sv.off_lights - sv.off_mats; tv.off_cdf = sv.off_cdf - sv.off_mats; tv.off_mats = 0u;
+    tb = smem;
+  }
   TravStackT<SPILL> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + blob_f4) + tid);
   stack.cap = p.stack_entries;
@@ -153,9 +163,6 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   uint32_t item_id = 0;
   uint32_t n_basic = 0, n_shadow = 0, n_err = 0, n_paths = 0;  // wave-uniform (ballot popcounts): live in SGPRs
   uint32_t path_basic = 0, path_shadow = 0;  // LIST mode per-path counts
-  bool pending = false;                      // this vertex has a shadow ray to traverse (connect_prepare)
-  ShadowRay sray; sray.org = F3(0, 0, 0); sray.dir = F3(0, 0, 1);
-  f3 nee = F3(0, 0, 0);                      // its contribution if unoccluded (PT.cpp:117-119 without the visibility)
   Visits vis_c = {0u, 0u, nullptr}, vis_s = {0u, 0u, nullptr};  // instrumented variant only
   if (COUNT) {  // wave-level loop-body counters (node-loop bodies, leaf-phase bodies) in the tail of the wave's LDS block
     uint32_t* wi = acc_n + 64;
@@ -207,11 +214,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
             rng = rng_seed(p.seed, py * p.width + px, sample);
             const float u0 = rng_f(rng), u1 = rng_f(rng);
             const float fx = float(px) + u0, fy = float(py) + u1;
-            const float vx = fx * p.res_y_inv * 2.0f - p.res_x * p.res_y_inv;
+            const float vx = fx * p.res_y_inv * 2.0f - p.res_x_res_y_inv;
             const float vy = fy * p.res_y_inv * 2.0f - 1.0f;
             dir = mulmv(v2w, normalize(F3(vx, vy, -p.focal_length_y)));
             org = nudge(cam_pos, cam_gnormal, dir);
-            bounce = false; radiance = F3(0, 0, 0); ps_pix &= 0xFC000000u; alive = true; pending = false;
+            bounce = false; radiance = F3(0, 0, 0); ps_pix &= 0xFC000000u; alive = true;
             path_basic = 0; path_shadow = 0;
             t_started = true;
           }
@@ -251,9 +258,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         const bool is_light = surf_is_light(sp);
         if (!bounce) {
           if (is_light && p.max_path > 0u) {  // PT.cpp:23-26: directly visible light, continue through it
-            const Material lm = load_material(sb, sv, sp.material_id);
+            const Material lm = load_material(tb, tv, sp.material_id);
             f3 le; float dens;
-            query_lsdf<FEAT>(sb, sv, light0, lm.light_id, -dir, le, dens);
+            query_lsdf<FEAT>(tb, tv, light0, lm.light_id, -dir, le, dens);
             radiance = radiance + le * p.lights;
             org = nudge(sp.position, sp.gnormal, dir);
           } else if (p.max_path < 2u) {
@@ -273,9 +280,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
           } else {
             const f3 ztp = tnum / bs_density;  // PT.cpp:66
             if (is_light) {  // PT.cpp:70-79: MIS-weighted emission, then continue through the light
-              const Material lm = load_material(sb, sv, sp.material_id);
+              const Material lm = load_material(tb, tv, sp.material_id);
               f3 le; float dens;
-              query_lsdf<FEAT>(sb, sv, light0, lm.light_id, omega, le, dens);
+              query_lsdf<FEAT>(tb, tv, light0, lm.light_id, omega, le, dens);
               float wInv = powb<FEAT>(dens, p.beta) / powb<FEAT>(fG * bs_density, p.beta) + 1.0f;
               if (!bs_finite) wInv = 1.0f;
               radiance = radiance + (le * ztp) / wInv;
@@ -300,9 +307,13 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
       MI_STAMP(2);  // querySurface + path logic
       if (do_vertex) {
         // ---- vertex x = sp: NEE (PT.cpp:41) then BSDF sample (PT.cpp:43-44) ----
-        const Material mat = load_material(sb, sv, sp.material_id);
+        const Material mat = load_material(tb, tv, sp.material_id);
         const f3 x_omega = -dir;
-        nee = connect_prepare<FEAT>(sb, sv, light0, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
+        // the vertex's shadow ray and its contribution if unoccluded (PT.cpp:117-119 without the visibility) live inside this block only:
+        // declared outside the loop they were loop-carried for the register allocator (10 VGPRs it then spilled around)
+        bool pending = false;
+        ShadowRay sray; sray.org = F3(0, 0, 0); sray.dir = F3(0, 0, 1);
+        const f3 nee = connect_prepare<FEAT>(tb, tv, light0, rng, mat, sp, x_omega, x_throughput, p.beta, pending, sray);
         if (pending) { t_shadow = true; ++path_shadow; }
         MI_STAMP(3);  // NEE set-up
         // a contribution that is exactly zero (delta BSDF at x, black surface) cannot change the sum whatever the
@@ -314,7 +325,6 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
           traverse<true, COUNT, QN, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
           if (COUNT) steps_mine_s = vis_s.nodes + vis_s.tris - s0;
           radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
-          pending = false;
         }
         MI_STAMP(4);  // shadow traversal
         const f3 x_position = sp.position, x_gnormal = sp.gnormal;
@@ -363,11 +373,17 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
 
   // ---- the wave's sums leave LDS once: partial[chunk][pixel] = (r, g, b, count) ----
   if (IMAGE && pool_end != 0u) {
-    const uint32_t px = tile_x0 + (lane & 7u), py = tile_y0 + (lane >> 3);
+    // the lane index and the accumulator addresses are derived afresh here (mbcnt, not threadIdx): kept from the prologue they were four VGPRs
+    // that lived — in scratch — across the whole path loop
+    const uint32_t le = rank_in(~0ull);
+    const uint32_t px = tile_x0 + (le & 7u), py = tile_y0 + (le >> 3);
     if (px < p.win_x0 + p.win_w && py < p.win_y0 + p.win_h) {
+      char* ab = reinterpret_cast<char*>(smem + blob_f4) + size_t(p.stack_entries) * kBlock * 4 + size_t(wave) * kAccBytesPerWave;
+      const double* er = reinterpret_cast<const double*>(ab);
+      const uint32_t* en = reinterpret_cast<const uint32_t*>(er + 192);
       double* o = p.partial + (size_t(chunk) * p.width * p.height + size_t(py) * p.width + px) * 4;
-      reinterpret_cast<double2*>(o)[0] = make_double2(acc_r[lane], acc_g[lane]);
-      reinterpret_cast<double2*>(o)[1] = make_double2(acc_b[lane], double(acc_n[lane]));
+      reinterpret_cast<double2*>(o)[0] = make_double2(er[le], er[64 + le]);
+      reinterpret_cast<double2*>(o)[1] = make_double2(er[128 + le], double(en[le]));
     }
   }
   if (FRAME && p.counters && lane < 4u * p.frame_count && acc_n[lane]) atomicAdd(&p.counters[32u + lane], (unsigned long long)acc_n[lane]);
@@ -470,7 +486,8 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
 
 // ---- host-callable launchers (declared in launch.h) ----
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
-  return (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0) + size_t(p.stack_entries) * kBlock * 4 + kWavesPerBlock * kAccBytesPerWave;
+  return (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : (p.lds_tables ? size_t(p.sv.blob_f4 - p.sv.off_mats) * 16 : 0)) +
+         size_t(p.stack_entries) * kBlock * 4 + kWavesPerBlock * kAccBytesPerWave;
 }
 
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bool count, uint32_t n_blocks, hipStream_t stream) {
@@ -490,12 +507,19 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
                                     f2 == 2 ? pt_megakernel<L, M, false, W, Q, (B) | 2, S> : pt_megakernel<L, M, false, W, Q, (B) | 3, S>)
 #define MI_PICK(L, M, W, Q, S) (feat == kFeatAll ? pt_megakernel<L, M, false, W, Q, kFeatAll, S> : (feat & kFeatLights) ? MI_PICK4(L, M, W, Q, S, kFeatLights) : MI_PICK4(L, M, W, Q, S, 0))
 #define MI_PICK_MODE(L, W, Q, S) (mode == 2 ? MI_PICK(L, 2, W, Q, S) : MI_PICK(L, 0, W, Q, S))
+#define MI_PICK4T(M, W, Q, B) (f2 == 0 ? pt_megakernel<false, M, false, W, Q, (B) | 0, true, true> : f2 == 1 ? pt_megakernel<false, M, false, W, Q, (B) | 1, true, true> : \
+                               f2 == 2 ? pt_megakernel<false, M, false, W, Q, (B) | 2, true, true> : pt_megakernel<false, M, false, W, Q, (B) | 3, true, true>)
+#define MI_PICKT(M, W, Q) (feat == kFeatAll ? pt_megakernel<false, M, false, W, Q, kFeatAll, true, true> : (feat & kFeatLights) ? MI_PICK4T(M, W, Q, kFeatLights) : MI_PICK4T(M, W, Q, 0))
+#define MI_PICK_HBM(W, Q) (p.lds_tables ? (mode == 2 ? MI_PICKT(2, W, Q) : MI_PICKT(0, W, Q)) : MI_PICK_MODE(false, W, Q, true))
     const int feat = (p.features & uint32_t(kFeatPow)) ? kFeatAll : int(p.features);  // a general beta is rare: only the general variant has pow
     const int f2 = feat & 3;
     if (lds_scene) fn = p.stack_in_lds ? MI_PICK_MODE(true, MI_WAVES_LDS, 0, false) : MI_PICK_MODE(true, MI_WAVES_LDS, 0, true);  // shallow tree: stack without the spill path
-    else if (p.wide_nodes == 2u) fn = MI_PICK_MODE(false, MI_WAVES_HBM, 0, true);
-    else if (large) fn = MI_PICK_MODE(false, MI_WAVES_HBM_LARGE, 2, true);
-    else fn = MI_PICK_MODE(false, MI_WAVES_HBM, 1, true);
+    else if (p.wide_nodes == 2u) fn = MI_PICK_HBM(MI_WAVES_HBM, 0);
+    else if (large) fn = MI_PICK_HBM(MI_WAVES_HBM_LARGE, 2);
+    else fn = MI_PICK_HBM(MI_WAVES_HBM, 1);
+#undef MI_PICK_HBM
+#undef MI_PICKT
+#undef MI_PICK4T
 #undef MI_PICK_MODE
 #undef MI_PICK
 #undef MI_PICK4

@@ -142,6 +142,7 @@ int fill_camera(const mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint3
   std::memcpy(p.cam_pos, cf.position, sizeof p.cam_pos);
   p.focal_length_y = cf.focal_length_y;
   p.res_x = float(width); p.res_y = float(height); p.res_y_inv = 1.0f / p.res_y;
+  { volatile float prod = p.res_x * p.res_y_inv; p.res_x_res_y_inv = prod; }  // one rounding, like the device's v_mul_f32
   p.width = width; p.height = height;
   return MI_OK;
 }
@@ -168,6 +169,12 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   if (h->scene.lights.size() != 1) f |= 8u;
   const char* e = std::getenv("MI_PT_PLAIN_KERNEL");
   p.features = (e && std::atoi(e) == 0) ? 15u : f;
+  // kernels that read the scene from HBM stage materials + lights + light CDF into LDS while that keeps the workgroup within the LDS share of
+  // its occupancy target (160 KB / 7 workgroups for the wide walk, / 6 otherwise); MI_PT_LDS_TABLES=0/1 overrides (A/B)
+  const size_t table_bytes = size_t(h->sv.blob_f4 - h->sv.off_mats) * 16;
+  const size_t share = (160u * 1024u) / (h->wide_nodes && !h->float_nodes ? 7u : 6u);
+  p.lds_tables = (!use_lds_scene(h) && table_bytes + size_t(h->stack_entries_hbm) * 1024 + 7424 <= share) ? 1u : 0u;
+  if (const char* t = std::getenv("MI_PT_LDS_TABLES")) p.lds_tables = (std::atoi(t) != 0 && !use_lds_scene(h) && table_bytes <= 48u * 1024u) ? 1u : 0u;
 }
 
 }  // namespace

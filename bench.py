@@ -380,7 +380,7 @@ def hbm_workload(ma, torch, args, seed):
             "value": segs / elapsed / 1e6, "unit": "Msamples/s", "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3,
             "Mpaths_per_s": paths / elapsed / 1e6, "Mrays_per_s": (segs + shadow) / elapsed / 1e6,
             "scene_bytes_in_hbm": li.scene_bytes, "node_records": {0: "32-byte quantised binary", 1: "64-byte quantised wide (4 grandchildren)", 2: "64-byte float binary"}[li.wide_nodes],
-            "tables_in_lds": bool(li.lds_tables), "scene_build_s": t_scene, "bvh_build_ms": info.build_ms,
+            "tables_in_lds": bool(li.lds_tables), "dynamic_fetch_traversal": bool(li.dynamic_fetch), "scene_build_s": t_scene, "bvh_build_ms": info.build_ms,
             "denom_equals_spp": bool((fb[..., 3] == float(spp)).all().item()),
             "roofline": rl}
 

@@ -62,6 +62,7 @@ struct RenderParams {
   uint32_t wide_nodes;     // HBM-resident kernels: 0 = 32-byte quantised binary nodes, 1 = 64-byte quantised wide nodes with the 7-wave
                            // register budget (large scenes), 2 = full-precision 64-byte binary nodes (grid too coarse for the scene)
   uint32_t features;       // kFeat* bits the scene and parameters need (pt_device.h): selects the kernel variant compiled without the rest
+  uint32_t dyn_traverse;   // LDS-resident kernels: closest-hit and shadow rays share one traversal loop with dynamic fetch (traverse_dyn)
   uint32_t lds_tables;     // HBM-resident kernels: materials, lights and the light CDF are staged into LDS by every workgroup (they fit kLdsTablesMaxF4)
   // sample range
   uint32_t spp, n_chunks, chunk_spp;

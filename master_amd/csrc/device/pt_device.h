@@ -247,6 +247,181 @@ MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, Stack& 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Unified traversal with dynamic fetch (LDS-resident scenes, full-precision binary nodes).
+//
+// In the plain loop trip every lane walks its own closest-hit ray, then — in a second loop — its own shadow ray: the wave pays the slowest
+// lane of each loop while 62 % of the lanes have a shadow ray at all (C2: 36.7 + 19.8 node bodies per trip for 11.0 + 4.4 node visits per
+// lane, profiles/r01/ab_postpone.txt).  Here the shadow ray of vertex k rides in the loop of trip k + 1 together with the closest-hit
+// rays of that trip, and it need not be walked by its owner: a lane that has finished its own closest-hit ray takes the next unstarted
+// shadow ray of the WAVE (rays are parked in LDS by their owners, results come back as one bit per owner in an LDS mask).  Closest-hit
+// rays never migrate — a live lane always starts with its own — so the hit record stays in the owner's registers.
+// Results do not depend on who walks a ray: the closest hit is the (t, id) minimum and occlusion is a boolean.
+constexpr uint32_t kDynRayBytes = 6u * 64u * 4u;                  // org.xyz, dir.xyz per owner lane, [field][lane]
+constexpr uint32_t kDynBytesPerWave = kDynRayBytes + 64u + 16u;  // + mailbox (owner lane per pool rank, one byte each) + occlusion mask
+typedef __attribute__((address_space(3))) float lds_f32;
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+struct DynLds { lds_f32* ray; lds_u8* mailbox; lds_u32* occl; };  // this wave's block
+
+MI_DEV void dyn_park_shadow_ray(const DynLds& d, uint32_t lane, f3 org, f3 dir) {
+  d.ray[lane] = org.x; d.ray[64 + lane] = org.y; d.ray[128 + lane] = org.z;
+  d.ray[192 + lane] = dir.x; d.ray[256 + lane] = dir.y; d.ray[320 + lane] = dir.z;
+}
+
+// alive: this lane has a closest-hit ray (org, dir) -> h.  pend: this lane parked a shadow ray (t in (0, 1], mesh mask) -> returns 1 if it is
+// unoccluded (meaningful for pend lanes only).  TH: idle lanes that trigger a refill from the pool.
+#ifdef MI_DYN_STATS
+#define MI_DYN_STAT(k) do { ++dyn_stats[k]; } while (0)
+#else
+#define MI_DYN_STAT(k) do { } while (0)
+#endif
+template <int QUANT, int NS, int TH, class Stack>
+MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, const DynLds& d, uint32_t lane, bool alive, f3 org, f3 dir, bool pend, Hit& h
+#ifdef MI_DYN_STATS
+                          , uint32_t* dyn_stats  // wave-uniform: [0] loop iterations, [1] node bodies, [2] leaf bodies, [3] refills, [4] rays fetched
+#endif
+) {
+  const float4* nodes = sb + sv.off_nodes;
+  const float4* tris = sb + sv.off_tris;
+  const uint4* __restrict__ qn = sv.qnodes;
+  const uint4* __restrict__ q4 = sv.qnodes4;
+  // QUANT: the boxes are 16-bit grid coordinates; the ray is moved into grid space once per ray (traverse() above)
+  const f3 glo = F3(sv.grid_lo[0], sv.grid_lo[1], sv.grid_lo[2]), gis = F3(sv.grid_inv_step[0], sv.grid_inv_step[1], sv.grid_inv_step[2]);
+  uint64_t pool = __ballot(pend);  // shadow rays nobody has started
+  if (lane < 2u) d.occl[lane] = 0u;
+  uint32_t mode = alive ? 1u : 0u;  // 0 idle, 1 own closest-hit ray, 2 a shadow ray of `owner`
+  uint32_t owner = lane;
+  f3 co = org, cd = dir;
+  float tmax = __builtin_inff();
+  RayBox rb = QUANT ? make_raybox((co - glo) * gis, cd * gis) : make_raybox(co, cd);
+  int sp = 0, node = 0;
+  for (;;) {
+    const uint64_t busy = __ballot(mode != 0u);
+    if (pool != 0ull && (busy == 0ull || __popcll(~busy) >= TH)) {
+      // ---- refill: the k-th idle lane takes the k-th shadow ray of the pool ----
+      const uint64_t idle = ~busy;
+      const uint32_t n_idle = uint32_t(__popcll(idle));
+      const bool in_pool = (pool >> lane) & 1ull;
+      const uint32_t rank_p = __builtin_amdgcn_mbcnt_hi(uint32_t(pool >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(pool), 0u));
+      if (in_pool) d.mailbox[rank_p] = uint8_t(lane);
+      const uint32_t n_pool = uint32_t(__popcll(pool));
+      pool &= ~__ballot(in_pool && rank_p < n_idle);
+      const uint32_t rank_i = __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
+      MI_DYN_STAT(3);
+#ifdef MI_DYN_STATS
+      dyn_stats[4] += n_idle < n_pool ? n_idle : n_pool;
+#endif
+      if (mode == 0u && rank_i < n_pool) {
+        owner = d.mailbox[rank_i];
+        co = F3(d.ray[owner], d.ray[64 + owner], d.ray[128 + owner]);
+        cd = F3(d.ray[192 + owner], d.ray[256 + owner], d.ray[320 + owner]);
+        rb = QUANT ? make_raybox((co - glo) * gis, cd * gis) : make_raybox(co, cd);
+        tmax = 1.0f; mode = 2u; sp = 0; node = 0;
+      }
+      continue;
+    }
+    if (busy == 0ull) break;
+    MI_DYN_STAT(0);
+#ifdef MI_DYN_STATS
+    if (__ballot(mode != 0u && node >= 0)) ++dyn_stats[1];
+    if (__ballot(mode != 0u && node < 0)) ++dyn_stats[2];
+#endif
+    if (mode != 0u) {
+      bool pop = false;
+      if (node >= 0) {
+        if (QUANT == 2) {
+          // wide quantised node: the (up to) four grandchildren, nearest first, the others pushed farthest first (traverse() above)
+          float t[4]; int l[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint4 a = q4[4 * node + k];
+            const f3 lo = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
+            const f3 hi = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
+            float tn;
+            const bool hk = box_test(lo, hi, rb, tmax, tn) && int(a.w) != kEmptyLink;
+            t[k] = hk ? tn : __builtin_inff();
+            l[k] = int(a.w);
+          }
+#define MI_CSWAP(a, b) do { const bool s_ = t[b] < t[a]; const float ta_ = s_ ? t[b] : t[a], tb_ = s_ ? t[a] : t[b]; \
+                            const int la_ = s_ ? l[b] : l[a], lb_ = s_ ? l[a] : l[b]; t[a] = ta_; t[b] = tb_; l[a] = la_; l[b] = lb_; } while (0)
+          MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); MI_CSWAP(1, 3); MI_CSWAP(1, 2);
+#undef MI_CSWAP
+          if (t[0] < __builtin_inff()) {
+            if (t[3] < __builtin_inff()) { stack.push(sp, uint32_t(l[3])); ++sp; }
+            if (t[2] < __builtin_inff()) { stack.push(sp, uint32_t(l[2])); ++sp; }
+            if (t[1] < __builtin_inff()) { stack.push(sp, uint32_t(l[1])); ++sp; }
+            node = l[0];
+          } else {
+            pop = true;
+          }
+        } else {
+          f3 lo0, hi0, lo1, hi1;
+          int l0, l1;
+          if (QUANT) {
+            const uint4 a = qn[2 * node], b = qn[2 * node + 1];
+            lo0 = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
+            hi0 = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
+            lo1 = F3(float(b.x & 0xFFFFu), float(b.x >> 16), float(b.y & 0xFFFFu));
+            hi1 = F3(float(b.y >> 16), float(b.z & 0xFFFFu), float(b.z >> 16));
+            l0 = int(a.w); l1 = int(b.w);
+          } else {
+            const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
+            lo0 = xyz(n0); hi0 = xyz(n1); lo1 = xyz(n2); hi1 = xyz(n3);
+            l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
+          }
+          float tn0, tn1;
+          const bool h0 = box_test(lo0, hi0, rb, tmax, tn0);
+          const bool h1 = box_test(lo1, hi1, rb, tmax, tn1);
+          if (h0 && h1) {
+            const bool sw = tn1 < tn0;
+            stack.push(sp, uint32_t(sw ? l0 : l1));
+            ++sp;
+            node = sw ? l1 : l0;
+          } else if (h0 || h1) {
+            node = h0 ? l0 : l1;
+          } else {
+            pop = true;
+          }
+        }
+      } else {
+        // Embree single-ray Moeller-Trumbore (tri_test above), both ray kinds: a closest-hit ray sees every geometry and keeps the (t, id)
+        // minimum; a shadow ray sees mesh geometry only and ends at the first hit with t <= 1
+        const uint32_t pos = uint32_t(~node);
+        const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
+        const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
+        const uint32_t id = __float_as_uint(c.y), gmask = __float_as_uint(c.z);
+        const f3 ng = cross(e2, e1);
+        const f3 C = v0 - co;
+        const f3 R = cross(C, cd);
+        const float den = dot(ng, cd);
+        const float absden = fabsf(den);
+        const float sgn = den < 0.0f ? -1.0f : 1.0f;
+        const float U = dot(R, e2) * sgn;
+        const float V = dot(R, e1) * sgn;
+        const float T = dot(ng, C) * sgn;
+        const bool seen = mode == 1u || (gmask & (1u << MI_ENTITY_MESH)) != 0u;
+        pop = true;
+        if (seen && den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absden && absden * 0.0f < T) {
+          const float t = T / absden;
+          if (mode == 2u) {
+            if (t <= 1.0f) { atomicOr((unsigned int*)&d.occl[owner >> 5], 1u << (owner & 31u)); mode = 0u; pop = false; }
+          } else if (t < h.t || (t == h.t && id < h.id)) {
+            h.t = t; h.u = U / absden; h.v = V / absden; h.id = id; h.pos = pos;
+            tmax = t;
+          }
+        }
+      }
+      if (pop) {
+        if (sp == 0) mode = 0u;
+        else { --sp; node = int(stack.pop(sp)); }
+      }
+    }
+  }
+  const uint32_t word = d.occl[lane >> 5];
+  return (word >> (lane & 31u)) & 1u ? 0.0f : 1.0f;
+}
+
 // Scene::querySurface (Scene.cpp:80-126).  SS = shading-record stride in float4 units (8 in HBM, 9 in the padded LDS copy:
 // with 128-byte records every lane's k-th float4 falls into the same 4 LDS banks).
 template <int SS = 8>

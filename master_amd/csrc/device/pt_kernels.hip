@@ -17,6 +17,8 @@
 // pixel accumulators: 3 x 64 doubles + 64 counts].
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pt_device.h"
 
 namespace mi {
@@ -53,6 +55,12 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 #ifndef MI_WAVES_LDS
 #define MI_WAVES_LDS 6
 #endif
+#ifndef MI_DYN_TH
+#define MI_DYN_TH 8  // idle lanes that trigger a refill of the unified traversal loop
+#endif
+// dynamic-fetch variants of the HBM-resident kernels: the parked rays cost 6.5 KB of LDS per workgroup.  Where six workgroups still fit a CU
+// (<= 27 306 B each) the 6-wave register budget wins (+2..5 %); where only five fit (LivingRoom: 3.2 KB of tables) the 5-wave budget
+// (96 VGPRs, no spills) wins by 9 % (profiles/r02/ab_dynamic_fetch.txt)
 #ifndef MI_WAVES_HBM
 #define MI_WAVES_HBM 6  // HBM-resident scenes (profiles/r01/ab_launch_bounds.txt): 6 waves = 5 waves +-1 % on small scenes, +3..9 % on 150-270 k triangles
 #endif
@@ -69,7 +77,9 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 // 1024-spp launch).  Ray / error counts are kept per frame (LDS atomics at path end; Technique::render fills statistics per frame).
 // TBL (kernels that read the scene from HBM): the small tables every vertex touches — materials, lights, light CDF — are staged into LDS by the
 // workgroup (LivingRoom: 65 materials = 3.2 KB), so the shading block's dependent reads (triangle -> material -> light) stop at the triangle.
-template <bool LDS_SCENE, int MODE, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true, bool TBL = false>
+// DYN: closest-hit and shadow rays of a trip share one traversal loop with dynamic fetch (traverse_dyn, pt_device.h);
+// the shadow ray of vertex k is resolved at the start of trip k + 1.
+template <bool LDS_SCENE, int MODE, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true, bool TBL = false, bool DYN = false>
 __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParams p) {
   constexpr bool LIST = MODE == 1, FRAME = MODE == 2, IMAGE = MODE == 0;
   extern __shared__ float4 smem[];
@@ -100,6 +110,18 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   double* acc_g = acc_r + 64;
   double* acc_b = acc_g + 64;
   uint32_t* acc_n = reinterpret_cast<uint32_t*>(acc_b + 64);
+  DynLds dyn;  // DYN: this wave's parked shadow rays, mailbox and occlusion mask, behind the accumulators of the workgroup
+  {
+    char* db = reinterpret_cast<char*>(smem + blob_f4) + size_t(p.stack_entries) * kBlock * 4 + size_t(kWavesPerBlock) * kAccBytesPerWave + size_t(wave) * kDynBytesPerWave;
+    dyn.ray = (lds_f32*)reinterpret_cast<float*>(db);
+    dyn.mailbox = (lds_u8*)reinterpret_cast<uint8_t*>(db + kDynRayBytes);
+    dyn.occl = (lds_u32*)reinterpret_cast<uint32_t*>(db + kDynRayBytes + 64);
+  }
+#ifdef MI_DYN_STATS
+  uint32_t dyn_stats[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  bool pend = false;          // DYN: this lane parked a shadow ray at its last vertex; nee_saved = its contribution if unoccluded
+  f3 nee_saved = F3(0, 0, 0);
   if (IMAGE) { acc_r[lane] = 0.0; acc_g[lane] = 0.0; acc_b[lane] = 0.0; acc_n[lane] = 0u; }
   if (FRAME) acc_n[lane] = 0u;  // per-frame counts of this wave: [frame][closest-hit rays, shadow rays, numeric errors, paths]
   __syncthreads();
@@ -237,12 +259,23 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
 
     MI_STAMP(0);  // regeneration
     uint32_t steps_mine_c = 0, steps_mine_s = 0;
+    Hit h;
+    h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+    if (DYN) {
+      // every lane of the wave takes part: its own closest-hit ray first, then unstarted shadow rays of the wave (Scene.cpp:151-203)
+#ifdef MI_DYN_STATS
+      const float visible = traverse_dyn<QN, NS, MI_DYN_TH>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h, dyn_stats);
+      ++dyn_stats[5];
+#else
+      const float visible = traverse_dyn<QN, NS, MI_DYN_TH>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h);
+#endif
+      if (pend) { radiance = radiance + nee_saved * visible; pend = false; }  // PT.cpp:41: radiance += _connect(...) of the previous vertex
+      MI_STAMP(1);
+    }
     if (alive) {
       // ---- Scene::intersect (Scene.cpp:182-203) ----
-      Hit h;
-      h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
       const uint32_t steps0 = vis_c.nodes + vis_c.tris;
-      traverse<false, COUNT, QN, NS, false>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);  // unmasked: PT's closest-hit rays see every geometry
+      if (!DYN) traverse<false, COUNT, QN, NS, false>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);  // unmasked: PT's closest-hit rays see every geometry
       MI_STAMP(1);  // closest-hit traversal
       ++path_basic;
       if (COUNT && h.id != 0xFFFFFFFFu) ++n_hits;
@@ -319,7 +352,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         // a contribution that is exactly zero (delta BSDF at x, black surface) cannot change the sum whatever the
         // visibility: the ray the reference would cast (and count, Scene.cpp:177) is counted but not traversed
         if (pending && !(nee.x != 0.0f || nee.y != 0.0f || nee.z != 0.0f)) pending = false;
-        if (pending) {
+        if (DYN) {
+          if (pending) { dyn_park_shadow_ray(dyn, lane, sray.org, sray.dir); pend = true; nee_saved = nee; }
+        } else if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
           const uint32_t s0 = vis_s.nodes + vis_s.tris;
           traverse<true, COUNT, QN, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
@@ -396,6 +431,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   }
 #ifdef MI_PHASE_TIMING
   if (lane == 0 && p.counters) for (int k = 0; k < 8; ++k) atomicAdd(&p.counters[16 + k], phase_t[k]);
+#endif
+#ifdef MI_DYN_STATS
+  if (DYN && lane == 0 && p.counters) for (int k = 0; k < 6; ++k) atomicAdd(&p.counters[16 + k], (unsigned long long)dyn_stats[k]);  // reported as phase_cycles[k]
 #endif
   if (COUNT && p.counters) {
     const uint32_t v0 = wave_sum(vis_c.nodes), v1 = wave_sum(vis_c.tris), v2 = wave_sum(vis_s.nodes), v3 = wave_sum(vis_s.tris), v4 = wave_sum(n_hits);
@@ -487,19 +525,25 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
 // ---- host-callable launchers (declared in launch.h) ----
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
   return (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : (p.lds_tables ? size_t(p.sv.blob_f4 - p.sv.off_mats) * 16 : 0)) +
-         size_t(p.stack_entries) * kBlock * 4 + kWavesPerBlock * kAccBytesPerWave;
+         size_t(p.stack_entries) * kBlock * 4 + kWavesPerBlock * kAccBytesPerWave + (p.dyn_traverse ? kWavesPerBlock * kDynBytesPerWave : 0);
 }
 
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bool count, uint32_t n_blocks, hipStream_t stream) {
-  const size_t lds = pt_lds_bytes(p, lds_scene);
+  size_t lds = pt_lds_bytes(p, lds_scene);
+  if (const char* e = std::getenv("MI_PT_LDS_PAD")) lds += size_t(std::atol(e));  // measurement only: more LDS per workgroup = fewer workgroups per CU
   void (*fn)(const RenderParams) = nullptr;
   const bool large = p.wide_nodes == 1u;
   const bool list = mode == 1;
-  if (!lds_scene && p.wide_nodes == 2u && (count || list)) {  // full-precision 64-byte nodes from HBM: scenes whose triangles are small against the 16-bit grid
+  const bool six = lds <= (160u * 1024u) / 6u;  // six workgroups of this LDS size fit a CU
+  if (!lds_scene && p.wide_nodes == 2u && (count || (list && !(p.dyn_traverse && p.lds_tables)))) {  // full-precision 64-byte nodes from HBM: scenes whose triangles are small against the 16-bit grid
     if (count) fn = pt_megakernel<false, 0, true, MI_WAVES_HBM, 0>;
     else fn = pt_megakernel<false, 1, false, MI_WAVES_HBM, 0>;
   } else
   if (count) fn = lds_scene ? pt_megakernel<true, 0, true, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, 0, true, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, 0, true, MI_WAVES_HBM, 1>);
+  else if (list && lds_scene && p.dyn_traverse && p.stack_in_lds) fn = pt_megakernel<true, 1, false, MI_WAVES_LDS, 0, kFeatAll, false, false, true>;  // per-path parity hook of the dynamic-fetch variant
+  else if (list && !lds_scene && p.dyn_traverse && p.lds_tables)
+    fn = p.wide_nodes == 2u ? pt_megakernel<false, 1, false, 5, 0, kFeatAll, true, true, true>
+                            : (large ? pt_megakernel<false, 1, false, 5, 2, kFeatAll, true, true, true> : pt_megakernel<false, 1, false, 5, 1, kFeatAll, true, true, true>);
   else if (list) fn = lds_scene ? pt_megakernel<true, 1, false, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, 1, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, 1, false, MI_WAVES_HBM, 1>);
   else {
     // the compiled feature set that covers the scene: any combination of Phong lobes and mirrors / glass with beta in {1, 2}, or everything
@@ -510,14 +554,26 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
 #define MI_PICK4T(M, W, Q, B) (f2 == 0 ? pt_megakernel<false, M, false, W, Q, (B) | 0, true, true> : f2 == 1 ? pt_megakernel<false, M, false, W, Q, (B) | 1, true, true> : \
                                f2 == 2 ? pt_megakernel<false, M, false, W, Q, (B) | 2, true, true> : pt_megakernel<false, M, false, W, Q, (B) | 3, true, true>)
 #define MI_PICKT(M, W, Q) (feat == kFeatAll ? pt_megakernel<false, M, false, W, Q, kFeatAll, true, true> : (feat & kFeatLights) ? MI_PICK4T(M, W, Q, kFeatLights) : MI_PICK4T(M, W, Q, 0))
-#define MI_PICK_HBM(W, Q) (p.lds_tables ? (mode == 2 ? MI_PICKT(2, W, Q) : MI_PICKT(0, W, Q)) : MI_PICK_MODE(false, W, Q, true))
+#define MI_PICK4TD(M, W, Q, B) (f2 == 0 ? pt_megakernel<false, M, false, W, Q, (B) | 0, true, true, true> : f2 == 1 ? pt_megakernel<false, M, false, W, Q, (B) | 1, true, true, true> : \
+                                f2 == 2 ? pt_megakernel<false, M, false, W, Q, (B) | 2, true, true, true> : pt_megakernel<false, M, false, W, Q, (B) | 3, true, true, true>)
+#define MI_PICKTD(M, W, Q) (feat == kFeatAll ? pt_megakernel<false, M, false, W, Q, kFeatAll, true, true, true> : (feat & kFeatLights) ? MI_PICK4TD(M, W, Q, kFeatLights) : MI_PICK4TD(M, W, Q, 0))
+#define MI_PICK_HBM(W, Q) (p.lds_tables ? (p.dyn_traverse ? (six ? (mode == 2 ? MI_PICKTD(2, 6, Q) : MI_PICKTD(0, 6, Q)) : (mode == 2 ? MI_PICKTD(2, 5, Q) : MI_PICKTD(0, 5, Q))) : (mode == 2 ? MI_PICKT(2, W, Q) : MI_PICKT(0, W, Q))) : MI_PICK_MODE(false, W, Q, true))
     const int feat = (p.features & uint32_t(kFeatPow)) ? kFeatAll : int(p.features);  // a general beta is rare: only the general variant has pow
     const int f2 = feat & 3;
+#define MI_PICK4D(M, B) (f2 == 0 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 0, false, false, true> : f2 == 1 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 1, false, false, true> : \
+                         f2 == 2 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 2, false, false, true> : pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 3, false, false, true>)
+#define MI_PICKD(M) (feat == kFeatAll ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, kFeatAll, false, false, true> : (feat & kFeatLights) ? MI_PICK4D(M, kFeatLights) : MI_PICK4D(M, 0))
+    if (lds_scene && p.dyn_traverse && p.stack_in_lds) fn = mode == 2 ? MI_PICKD(2) : MI_PICKD(0);  // unified traversal with dynamic fetch
+    else
     if (lds_scene) fn = p.stack_in_lds ? MI_PICK_MODE(true, MI_WAVES_LDS, 0, false) : MI_PICK_MODE(true, MI_WAVES_LDS, 0, true);  // shallow tree: stack without the spill path
     else if (p.wide_nodes == 2u) fn = MI_PICK_HBM(MI_WAVES_HBM, 0);
     else if (large) fn = MI_PICK_HBM(MI_WAVES_HBM_LARGE, 2);
     else fn = MI_PICK_HBM(MI_WAVES_HBM, 1);
 #undef MI_PICK_HBM
+#undef MI_PICKTD
+#undef MI_PICK4TD
+#undef MI_PICKD
+#undef MI_PICK4D
 #undef MI_PICKT
 #undef MI_PICK4T
 #undef MI_PICK_MODE

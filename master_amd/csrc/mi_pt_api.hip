@@ -174,7 +174,20 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   const size_t table_bytes = size_t(h->sv.blob_f4 - h->sv.off_mats) * 16;
   const size_t share = (160u * 1024u) / (h->wide_nodes && !h->float_nodes ? 7u : 6u);
   p.lds_tables = (!use_lds_scene(h) && table_bytes + size_t(h->stack_entries_hbm) * 1024 + 7424 <= share) ? 1u : 0u;
+  {  // with the dynamic-fetch traversal (below) the parked rays take 6.5 KB more and five or six workgroups share a CU: the tables may use that room
+    const char* d = std::getenv("MI_PT_DYN");
+    if (!use_lds_scene(h) && !(d && std::atoi(d) == 0) && table_bytes + size_t(h->stack_entries_hbm) * 1024 + 7424 + 6464 <= (160u * 1024u) / 5u) p.lds_tables = 1u;
+  }
   if (const char* t = std::getenv("MI_PT_LDS_TABLES")) p.lds_tables = (std::atoi(t) != 0 && !use_lds_scene(h) && table_bytes <= 48u * 1024u) ? 1u : 0u;
+  {  // unified traversal with dynamic fetch (traverse_dyn): on for scenes read from HBM (+24..53 %: the loop trip is a dependent fetch, and one
+     // loop over closest-hit + shadow rays with refill needs less than half the trips), off for LDS-resident scenes (-9 % at equal occupancy: the
+     // loop is instruction-bound there and leaf tests run at 14 % lane utilisation either way); MI_PT_DYN=0/1 overrides (profiles/r02/ab_dynamic_fetch.txt)
+    const char* d = std::getenv("MI_PT_DYN");
+    const bool lds = use_lds_scene(h);
+    const bool want = d ? std::atoi(d) != 0 : !lds;
+    if (lds) p.dyn_traverse = (want && h->sv.n_nodes >= 1u && h->stack_fits_lds) ? 1u : 0u;
+    else p.dyn_traverse = (want && h->sv.n_nodes >= 1u && p.lds_tables) ? 1u : 0u;
+  }
 }
 
 }  // namespace
@@ -576,7 +589,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
     li.n_blocks = uint32_t(n_blocks); li.n_chunks = 1; li.chunk_spp = 1; li.frame_tiles_per_wave = tiles_per_wave; li.frames = n_frames;
     li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
-    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u;
+    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = (p.dyn_traverse && !h->instrumented) ? 1u : 0u;
     li.partial_bytes = 0;
     li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
     if (stats) return collect_stats(h, stream, stats, ev);
@@ -615,7 +628,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
     li.n_blocks = uint32_t(n_blocks); li.n_chunks = p.n_chunks; li.chunk_spp = p.chunk_spp;
     li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
-    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u;
+    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = (p.dyn_traverse && !h->instrumented) ? 1u : 0u;
     li.partial_bytes = uint64_t(p.n_chunks) * win.w * win.h * 32ull;
     li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
   }

@@ -48,7 +48,7 @@ def test_every_entry_point_cites_the_reference():
 def test_struct_sizes():
     assert C.sizeof(ma.Material) == 48 and C.sizeof(ma.Light) == 80 and C.sizeof(ma.Camera) == 40
     assert C.sizeof(ma.SurfacePoint) == 64 and C.sizeof(ma.BvhNode) == 64 and C.sizeof(ma.PtParams) == 24
-    assert C.sizeof(ma.LaunchInfo) == 56
+    assert C.sizeof(ma.LaunchInfo) == 64
     hdr = open(os.path.join(ROOT, "include", "mi_pt.h")).read()
     assert "#define MI_PT_MAX_FRAMES_PER_BATCH %d" % ma.MAX_FRAMES_PER_BATCH in hdr and "#define MI_PT_BATCHES_IN_FLIGHT %d" % ma.BATCHES_IN_FLIGHT in hdr
 

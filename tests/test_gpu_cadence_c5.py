@@ -184,3 +184,41 @@ def test_frame_mode_writes_the_same_frame_as_the_accumulating_kernel(monkeypatch
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (w, h, win, shard, tiles)
             assert ref_st == (pt.last_stats.num_paths, pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays, pt.last_stats.numeric_errors)
         monkeypatch.delenv("MI_PT_FRAME_TILES")
+
+
+# ---- unified traversal with dynamic fetch (traverse_dyn): the default for scenes read from HBM ----
+@pytest.mark.parametrize("name", ["LivingRoomLit", "MetalRings", "CornellBoxSpecular", "MirrorBalls", "soup20000", "CornellBoxDiffuse", "TestCaseFurnace", "atrium:120000"])
+def test_dynamic_fetch_traversal_is_bit_identical_per_path(monkeypatch, name):
+    """One loop over the closest-hit rays of trip k + 1 and the shadow rays of trip k, idle lanes fetching unstarted shadow rays of the wave: who
+    walks a ray cannot matter — per-path radiance and ray counts equal the plain kernel's and the oracle's bit for bit; images differ by the
+    order of a pixel's FP64 sum at most.  Both node formats of HBM-resident scenes, the wide walk (>= 100 000 triangles) and the LDS-resident
+    variant (off by default there) are covered."""
+    if name.startswith("soup"):
+        s = sb.random_soup(int(name[4:]), seed=11)
+    elif name.startswith("atrium"):
+        s = sb.load(name)
+    else:
+        s = load_scene(name)
+    pt = ma.PathTracing(s, max_path=9)
+    w, h, spp = 48, 40, 6
+    xy = np.stack(np.meshgrid(np.arange(w), np.arange(h)), -1).reshape(-1, 2).astype(np.uint32)
+    xy, si = np.tile(xy, (spp, 1)), np.repeat(np.arange(spp, dtype=np.uint64), w * h)
+    out = {}
+    for dyn in ("0", "1"):
+        monkeypatch.setenv("MI_PT_DYN", dyn)
+        rad, cnt = pt.trace_paths(w, h, xy, si, seed=21)
+        img = pt.render_rgbn(w, h, spp=spp, seed=21)
+        li = pt.last_launch()
+        frame = pt.render_rgbn(w, h, spp=1, seed=21, sample_offset=3)
+        out[dyn] = (rad, cnt, img, frame, (pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays), li.dynamic_fetch)
+    a, b = out["0"], out["1"]
+    assert a[5] == 0 and b[5] == 1
+    same = np.isclose(a[0], b[0], rtol=0, atol=0, equal_nan=True)
+    assert same.all() and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2][..., 3], b[2][..., 3]) and np.allclose(a[2], b[2], rtol=1.2e-7, atol=0, equal_nan=True)
+    assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)) and a[4] == b[4]  # one sample per pixel: nothing to reorder
+    orad, ocnt = oracle.Oracle(s, max_path=9).trace_paths(w, h, xy, si, seed=21)
+    assert np.isclose(b[0], orad, rtol=0, atol=0, equal_nan=True).all() and np.array_equal(b[1], ocnt)
+    monkeypatch.delenv("MI_PT_DYN")
+    pt.render_rgbn(w, h, spp=2, seed=1)
+    assert pt.last_launch().dynamic_fetch == (0 if pt.get_kernel() == ma.KERNEL_MEGA_LDS else 1)

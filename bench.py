@@ -50,8 +50,14 @@ def algorithmic_bytes_per_sample(st, wavefront=False, node_bytes=64.0):
     b = 152.0 * h + node_bytes * (n_c + n_s) + 48.0 * (t_c + t_s) + 32.0 * s + 16.0 / lbar + (192.0 if wavefront else 0.0)
     eff_c = (st.nodes_closest + st.tris_closest) / (64.0 * st.wave_steps_closest) if st.wave_steps_closest else None
     eff_s = (st.nodes_shadow + st.tris_shadow) / (64.0 * st.wave_steps_shadow) if st.wave_steps_shadow else None
-    return b, dict(h=h, s=s, Lbar=lbar, N=n_c, T=t_c, N_shadow_per_segment=n_s, T_shadow_per_segment=t_s,
-                   simd_efficiency_closest_traversal=eff_c, simd_efficiency_shadow_traversal=eff_s)
+    terms = dict(h=h, s=s, Lbar=lbar, N=n_c, T=t_c, N_shadow_per_segment=n_s, T_shadow_per_segment=t_s)
+    if st.wave_steps_closest and not st.wave_steps_shadow and st.nodes_shadow:
+        # dynamic-fetch traversal: ONE loop walks the closest-hit rays of a trip and the shadow rays of the trip before, idle lanes refill from the wave's pool
+        terms["simd_efficiency_unified_traversal"] = (st.nodes_closest + st.tris_closest + st.nodes_shadow + st.tris_shadow) / (64.0 * st.wave_steps_closest)
+        terms["simd_efficiency_closest_traversal"] = terms["simd_efficiency_shadow_traversal"] = terms["simd_efficiency_unified_traversal"]
+    else:
+        terms["simd_efficiency_closest_traversal"], terms["simd_efficiency_shadow_traversal"] = eff_c, eff_s
+    return b, terms
 
 
 def effective_cpus():

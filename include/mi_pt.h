@@ -139,7 +139,9 @@ typedef struct mi_pt_stats {
   uint64_t nodes_shadow, tris_shadow;    /* the same for shadow rays                                 */
   uint64_t num_hits;                     /* closest-hit rays that hit a surface                      */
   uint64_t wave_steps_closest;           /* sum over waves and loop trips of the SLOWEST lane's traversal steps */
-  uint64_t wave_steps_shadow;            /* (nodes + triangles); 64 x this vs the per-lane totals = SIMD efficiency */
+  uint64_t wave_steps_shadow;            /* (nodes + triangles); 64 x this vs the per-lane totals = SIMD efficiency.  With the dynamic-fetch
+                                            traversal (mi_pt_launch_info::dynamic_fetch) closest-hit and shadow rays share one loop:
+                                            wave_steps_closest counts its trips, wave_steps_shadow is 0 */
   /* diagnostic builds only (-DMI_PHASE_TIMING): shader cycles summed over waves per phase of the loop trip:
    * 0 regeneration, 1 closest-hit traversal, 2 querySurface + path logic, 3 NEE set-up, 4 shadow traversal,
    * 5 BSDF sample, 6 commit, 7 loop overhead.  Zero in the product build. */

@@ -276,8 +276,10 @@ MI_DEV void dyn_park_shadow_ray(const DynLds& d, uint32_t lane, f3 org, f3 dir) 
 #else
 #define MI_DYN_STAT(k) do { } while (0)
 #endif
-template <int QUANT, int NS, int TH, class Stack>
-MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, const DynLds& d, uint32_t lane, bool alive, f3 org, f3 dir, bool pend, Hit& h
+// COUNT (instrumented variant): per-lane node / triangle visits by ray kind (whoever walks the ray) and the loop trips of the wave
+template <int QUANT, int NS, int TH, bool COUNT = false, class Stack>
+MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, const DynLds& d, uint32_t lane, bool alive, f3 org, f3 dir, bool pend, Hit& h,
+                          Visits* vis_c = nullptr, Visits* vis_s = nullptr, uint32_t* wave_trips = nullptr
 #ifdef MI_DYN_STATS
                           , uint32_t* dyn_stats  // wave-uniform: [0] loop iterations, [1] node bodies, [2] leaf bodies, [3] refills, [4] rays fetched
 #endif
@@ -322,6 +324,11 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
       continue;
     }
     if (busy == 0ull) break;
+    if (COUNT) {
+      ++*wave_trips;
+      if (mode == 1u) { if (node >= 0) ++vis_c->nodes; else ++vis_c->tris; }
+      if (mode == 2u) { if (node >= 0) ++vis_s->nodes; else ++vis_s->tris; }
+    }
     MI_DYN_STAT(0);
 #ifdef MI_DYN_STATS
     if (__ballot(mode != 0u && node >= 0)) ++dyn_stats[1];

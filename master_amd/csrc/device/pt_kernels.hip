@@ -264,10 +264,12 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
     if (DYN) {
       // every lane of the wave takes part: its own closest-hit ray first, then unstarted shadow rays of the wave (Scene.cpp:151-203)
 #ifdef MI_DYN_STATS
-      const float visible = traverse_dyn<QN, NS, MI_DYN_TH>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h, dyn_stats);
+      const float visible = traverse_dyn<QN, NS, MI_DYN_TH, false>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h, nullptr, nullptr, nullptr, dyn_stats);
       ++dyn_stats[5];
 #else
-      const float visible = traverse_dyn<QN, NS, MI_DYN_TH>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h);
+      uint32_t trips = 0;
+      const float visible = traverse_dyn<QN, NS, MI_DYN_TH, COUNT>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h, &vis_c, &vis_s, &trips);
+      if (COUNT) trips_c += trips;  // wave-uniform: the trips of the unified loop (closest-hit and shadow rays together)
 #endif
       if (pend) { radiance = radiance + nee_saved * visible; pend = false; }  // PT.cpp:41: radiance += _connect(...) of the previous vertex
       MI_STAMP(1);
@@ -535,11 +537,15 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
   const bool large = p.wide_nodes == 1u;
   const bool list = mode == 1;
   const bool six = lds <= (160u * 1024u) / 6u;  // six workgroups of this LDS size fit a CU
-  if (!lds_scene && p.wide_nodes == 2u && (count || (list && !(p.dyn_traverse && p.lds_tables)))) {  // full-precision 64-byte nodes from HBM: scenes whose triangles are small against the 16-bit grid
+  if (!lds_scene && p.wide_nodes == 2u && ((count || list) && !(p.dyn_traverse && p.lds_tables))) {  // full-precision 64-byte nodes from HBM: scenes whose triangles are small against the 16-bit grid
     if (count) fn = pt_megakernel<false, 0, true, MI_WAVES_HBM, 0>;
     else fn = pt_megakernel<false, 1, false, MI_WAVES_HBM, 0>;
   } else
-  if (count) fn = lds_scene ? pt_megakernel<true, 0, true, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, 0, true, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, 0, true, MI_WAVES_HBM, 1>);
+  if (count && p.dyn_traverse && !lds_scene && p.lds_tables)  // instrumented dynamic-fetch variants (5-wave budget)
+    fn = p.wide_nodes == 2u ? pt_megakernel<false, 0, true, 5, 0, kFeatAll, true, true, true>
+                            : (large ? pt_megakernel<false, 0, true, 5, 2, kFeatAll, true, true, true> : pt_megakernel<false, 0, true, 5, 1, kFeatAll, true, true, true>);
+  else if (count && p.dyn_traverse && lds_scene && p.stack_in_lds) fn = pt_megakernel<true, 0, true, MI_WAVES_LDS, 0, kFeatAll, false, false, true>;
+  else if (count) fn = lds_scene ? pt_megakernel<true, 0, true, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, 0, true, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, 0, true, MI_WAVES_HBM, 1>);
   else if (list && lds_scene && p.dyn_traverse && p.stack_in_lds) fn = pt_megakernel<true, 1, false, MI_WAVES_LDS, 0, kFeatAll, false, false, true>;  // per-path parity hook of the dynamic-fetch variant
   else if (list && !lds_scene && p.dyn_traverse && p.lds_tables)
     fn = p.wide_nodes == 2u ? pt_megakernel<false, 1, false, 5, 0, kFeatAll, true, true, true>

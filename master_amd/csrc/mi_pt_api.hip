@@ -589,7 +589,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
     li.n_blocks = uint32_t(n_blocks); li.n_chunks = 1; li.chunk_spp = 1; li.frame_tiles_per_wave = tiles_per_wave; li.frames = n_frames;
     li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
-    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = (p.dyn_traverse && !h->instrumented) ? 1u : 0u;
+    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = p.dyn_traverse ? 1u : 0u;
     li.partial_bytes = 0;
     li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
     if (stats) return collect_stats(h, stream, stats, ev);
@@ -628,7 +628,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
     li.n_blocks = uint32_t(n_blocks); li.n_chunks = p.n_chunks; li.chunk_spp = p.chunk_spp;
     li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
-    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = (p.dyn_traverse && !h->instrumented) ? 1u : 0u;
+    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = p.dyn_traverse ? 1u : 0u;
     li.partial_bytes = uint64_t(p.n_chunks) * win.w * win.h * 32ull;
     li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
   }

@@ -2,7 +2,12 @@
 // Replaces save_exr / load_exr (exr.cpp:177-232, 245-297), which need libIlmImf (absent):
 // float channels R, G, B, denom; rows flipped so EXR line 0 is the top of the image
 // (exr.cpp:207-214); run metadata as string attributes (exr.cpp:196-198).
-// Written files are uncompressed (compression = NO_COMPRESSION), single part, version 2.
+// Written files are uncompressed (compression = NO_COMPRESSION), single part, version 2 (long-name flag when a metadata key needs it).
+// The reader also takes what the reference itself writes: save_exr uses OpenEXR's default header, i.e. ZIP_COMPRESSION (16 scan lines per
+// chunk, zlib + byte predictor + even/odd interleave); ZIPS (one line per chunk) and RLE come with it.  So `master continue / merge /
+// errors` inputs and the reference's baked images can be loaded.
+#include <zlib.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +36,37 @@ float half_to_float(uint16_t h) {
   float f; std::memcpy(&f, &bits, 4); return f;
 }
 
+// OpenEXR's post-processing of a compressed chunk (ImfZip / ImfRle): undo the byte predictor, then merge the two halves (even / odd bytes)
+void unpredict_and_interleave(std::vector<uint8_t>& t, uint8_t* out) {
+  const size_t n = t.size();
+  for (size_t i = 1; i < n; ++i) t[i] = uint8_t(int(t[i - 1]) + int(t[i]) - 128);
+  const size_t half = (n + 1) / 2;
+  for (size_t i = 0; i < half; ++i) { out[2 * i] = t[i]; if (2 * i + 1 < n) out[2 * i + 1] = t[half + i]; }
+}
+
+// one chunk -> `expect` raw bytes.  compression: 0 none, 1 RLE, 2 ZIPS, 3 ZIP.  A chunk whose stored size equals `expect` is stored raw.
+bool decode_chunk(int compression, const uint8_t* src, size_t size, size_t expect, std::vector<uint8_t>& out) {
+  out.resize(expect);
+  if (compression == 0 || size == expect) { if (size != expect) return false; std::memcpy(out.data(), src, expect); return true; }
+  std::vector<uint8_t> tmp(expect);
+  if (compression == 2 || compression == 3) {
+    uLongf got = uLongf(expect);
+    if (uncompress(tmp.data(), &got, src, uLong(size)) != Z_OK || got != expect) return false;
+  } else if (compression == 1) {  // RLE: signed count byte: n >= 0 -> repeat next byte n + 1 times; n < 0 -> copy -n literal bytes
+    size_t i = 0, o = 0;
+    while (i < size) {
+      const int c = int8_t(src[i++]);
+      if (c < 0) { const size_t k = size_t(-c); if (i + k > size || o + k > expect) return false; std::memcpy(&tmp[o], &src[i], k); i += k; o += k; }
+      else { const size_t k = size_t(c) + 1; if (i >= size || o + k > expect) return false; std::memset(&tmp[o], src[i++], k); o += k; }
+    }
+    if (o != expect) return false;
+  } else {
+    return false;
+  }
+  unpredict_and_interleave(tmp, out.data());
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -40,7 +76,12 @@ int mi_exr_save_rgbn(const char* path, uint32_t width, uint32_t height, const fl
   if (!path || !rgbn || width == 0 || height == 0 || (n_meta && (!meta_keys || !meta_values)))
     return mi::fail(MI_ERR_INVALID_ARGUMENT, "mi_exr_save_rgbn: bad argument");
   std::vector<uint8_t> o;
-  const uint8_t magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};
+  uint8_t magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};
+  for (uint32_t i = 0; i < n_meta; ++i) {  // attribute names: up to 31 bytes, up to 255 with the long-name flag (version field bit 10)
+    const size_t len = meta_keys[i] ? std::strlen(meta_keys[i]) : 0;
+    if (len > 255) return mi::fail(MI_ERR_INVALID_ARGUMENT, "mi_exr_save_rgbn: a metadata key is longer than 255 bytes");
+    if (len > 31) magic[5] |= 0x04;
+  }
   put_bytes(o, magic, 8);
   {  // chlist: channels sorted by name: B, G, R, denom
     std::vector<uint8_t> ch;
@@ -129,7 +170,7 @@ int mi_exr_load_rgbn(const char* path, uint32_t* width, uint32_t* height, float*
     else if (name == "compression" && size == 1) compression = d[o];
     o += size_t(size);
   }
-  if (compression != 0) return mi::fail(MI_ERR_UNSUPPORTED, bad + "only uncompressed EXR files are supported.");
+  if (compression < 0 || compression > 3) return mi::fail(MI_ERR_UNSUPPORTED, bad + "only uncompressed, RLE, ZIPS and ZIP scan-line files are supported.");
   const int64_t w = int64_t(win[2]) - win[0] + 1, h = int64_t(win[3]) - win[1] + 1;
   if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || chans.empty()) return mi::fail(MI_ERR_IO, bad + "bad data window.");
   int dst_of[64]; size_t line_size = 0;
@@ -140,27 +181,36 @@ int mi_exr_load_rgbn(const char* path, uint32_t* width, uint32_t* height, float*
     if (chans[c].type != 1 && chans[c].type != 2 && chans[c].type != 0) return mi::fail(MI_ERR_UNSUPPORTED, bad + "bad channel type.");
     line_size += size_t(w) * (chans[c].type == 1 ? 2 : 4);
   }
-  if (line_size == 0 || size_t(h) > d.size() / line_size) return mi::fail(MI_ERR_IO, bad + "truncated pixel data.");  // also bounds the allocation by the file size
+  const int64_t lines_per_chunk = compression == 3 ? 16 : 1, n_chunks = (h + lines_per_chunk - 1) / lines_per_chunk;
+  if (line_size == 0 || (compression == 0 && size_t(h) > d.size() / line_size) || size_t(n_chunks) > d.size() / 8)
+    return mi::fail(MI_ERR_IO, bad + "truncated pixel data.");  // also bounds the allocation by the file size (a compressed line needs >= 8 bytes of chunk header)
+  if (size_t(w) * size_t(h) > (size_t(1) << 31)) return mi::fail(MI_ERR_UNSUPPORTED, bad + "image too large.");
   float* out = static_cast<float*>(std::calloc(size_t(w) * size_t(h) * 4, sizeof(float)));
   if (!out) return mi::fail(MI_ERR_OUT_OF_MEMORY, "out of memory");
   bool has_denom = false;
   for (const Chan& c : chans) has_denom |= c.name == "denom";
-  for (int64_t y = 0; y < h; ++y) {
+  std::vector<uint8_t> raw;
+  for (int64_t k = 0; k < n_chunks; ++k) {
     uint64_t off;
-    if (o + size_t(y) * 8 + 8 > d.size()) { std::free(out); return mi::fail(MI_ERR_IO, bad + "truncated offset table."); }
-    std::memcpy(&off, &d[o + size_t(y) * 8], 8);
-    if (off > d.size() || 8 + line_size > d.size() - off) { std::free(out); return mi::fail(MI_ERR_IO, bad + "truncated pixel data."); }
-    int32_t yy; std::memcpy(&yy, &d[off], 4);
-    const int64_t row = (h - 1) - (int64_t(yy) - win[1]);  // flip back: EXR line 0 = top
-    if (row < 0 || row >= h) { std::free(out); return mi::fail(MI_ERR_IO, bad + "bad scan line."); }
-    size_t p = off + 8;
-    for (size_t c = 0; c < chans.size(); ++c) {
-      for (int64_t x = 0; x < w; ++x) {
-        float v;
-        if (chans[c].type == 1) { uint16_t hv; std::memcpy(&hv, &d[p], 2); p += 2; v = half_to_float(hv); }
-        else if (chans[c].type == 2) { std::memcpy(&v, &d[p], 4); p += 4; }
-        else { uint32_t uv; std::memcpy(&uv, &d[p], 4); p += 4; v = float(uv); }
-        if (dst_of[c] >= 0) out[(size_t(row) * size_t(w) + size_t(x)) * 4 + size_t(dst_of[c])] = v;
+    if (o + size_t(k) * 8 + 8 > d.size()) { std::free(out); return mi::fail(MI_ERR_IO, bad + "truncated offset table."); }
+    std::memcpy(&off, &d[o + size_t(k) * 8], 8);
+    if (off > d.size() || 8 > d.size() - off) { std::free(out); return mi::fail(MI_ERR_IO, bad + "truncated pixel data."); }
+    int32_t yy, stored; std::memcpy(&yy, &d[off], 4); std::memcpy(&stored, &d[off + 4], 4);
+    const int64_t first = int64_t(yy) - win[1];
+    if (first < 0 || first >= h || stored < 0 || size_t(stored) > d.size() - off - 8) { std::free(out); return mi::fail(MI_ERR_IO, bad + "bad scan line."); }
+    const int64_t lines = h - first < lines_per_chunk ? h - first : lines_per_chunk;
+    if (!decode_chunk(compression, &d[off + 8], size_t(stored), size_t(lines) * line_size, raw)) { std::free(out); return mi::fail(MI_ERR_IO, bad + "corrupt scan-line chunk."); }
+    size_t p = 0;
+    for (int64_t l = 0; l < lines; ++l) {
+      const int64_t row = (h - 1) - (first + l);  // flip back: EXR line 0 = top
+      for (size_t c = 0; c < chans.size(); ++c) {
+        for (int64_t x = 0; x < w; ++x) {
+          float v;
+          if (chans[c].type == 1) { uint16_t hv; std::memcpy(&hv, &raw[p], 2); p += 2; v = half_to_float(hv); }
+          else if (chans[c].type == 2) { std::memcpy(&v, &raw[p], 4); p += 4; }
+          else { uint32_t uv; std::memcpy(&uv, &raw[p], 4); p += 4; v = float(uv); }
+          if (dst_of[c] >= 0) out[(size_t(row) * size_t(w) + size_t(x)) * 4 + size_t(dst_of[c])] = v;
+        }
       }
     }
   }

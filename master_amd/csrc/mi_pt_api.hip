@@ -999,31 +999,51 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   std::memcpy(w.w2v, fr.world_to_view, sizeof w.w2v);
   std::memcpy(w.sphere, h->sphere, sizeof w.sphere);
   std::memcpy(w.sky_horizon, h->sky_horizon, sizeof w.sky_horizon); std::memcpy(w.sky_zenith, h->sky_zenith, sizeof w.sky_zenith);
+  if (width > 65535u || height > 65535u)  // the staged form packs a path's pixel as (y << 16) | x in its info record (bpt_kernels.hip)
+    return fail(MI_ERR_UNSUPPORTED, "BPT: width and height must not exceed 65535");
   uint64_t lanes = total_lanes < (1ull << 20) ? total_lanes : (1ull << 20);  // up to 1 M paths per launch
   lanes = (lanes + 255) / 256 * 256;
   const bool staged = bpt_staged();
-  uint64_t budget = staged ? (16ull << 30) : (24ull << 30);  // vertex slabs: 3 x 16 GB (staged) or 24 GB of the 288 GB
+  // vertex slabs: at most 3 x 16 GB (staged) or 24 GB, and at most 40 % of what the device has free right now (another process may share
+  // the GPU; a smaller GPU has less): the capacity per sub-path shrinks, long paths then go through the slice path of bpt_launch
+  uint64_t budget = staged ? (16ull << 30) : (24ull << 30);
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+      const uint64_t have = staged ? h->bpt_arena_bytes : h->bpt_slab_bytes;  // what this handle already holds counts as available to it
+      const uint64_t share = (uint64_t(free_b) + have) * 2 / 5 / (staged ? 3 : 1);
+      if (share < budget) budget = share;
+    }
+  }
   if (const char* e = std::getenv("MI_BPT_SLAB_MB")) { const long long v = std::atoll(e); if (v > 0) budget = uint64_t(v) << 20; }
   uint64_t cap = budget / (lanes * 112ull);
   if (cap > 1024) cap = 1024;
   if (cap < 16) cap = 16;
-  w.max_vertices = uint32_t(cap);
-  if (staged) {
-    const size_t slab = size_t(lanes) * cap * 112;
-    const size_t need = 3 * slab + size_t(lanes) * (cap * 16 + 32 + 4 + 1) + 8192;
-    rc = ensure(reinterpret_cast<void**>(&h->bpt_arena), &h->bpt_arena_bytes, need);
-    if (rc) return rc;
-    char* a = h->bpt_arena;
-    auto take = [&](size_t bytes) { char* r = a; a += (bytes + 255) / 256 * 256; return r; };
-    w.lslab = reinterpret_cast<float4*>(take(slab)); w.eslab = reinterpret_cast<float4*>(take(slab)); w.nslab = reinterpret_cast<float4*>(take(slab));
-    w.emission = reinterpret_cast<float4*>(take(size_t(lanes) * cap * 16));
-    w.info = reinterpret_cast<uint4*>(take(size_t(lanes) * 32));
-    w.item_offset = reinterpret_cast<uint32_t*>(take((size_t(lanes) + 1) * 4));
-    w.scan_tmp = reinterpret_cast<uint32_t*>(take((size_t(lanes) / 2048 + 2) * 4));
-  } else {
-    rc = ensure(reinterpret_cast<void**>(&h->bpt_slab), &h->bpt_slab_bytes, size_t(lanes) * cap * 112);
-    if (rc) return rc;
-    w.slab = h->bpt_slab;
+  for (;;) {  // an allocation that fails is retried at half the capacity, then at half the paths per launch, down to 16 vertices x 256 paths
+    w.max_vertices = uint32_t(cap);
+    if (staged) {
+      const size_t slab = size_t(lanes) * cap * 112;
+      const size_t need = 3 * slab + size_t(lanes) * (cap * 16 + 32 + 4 + 1) + 8192;
+      rc = ensure(reinterpret_cast<void**>(&h->bpt_arena), &h->bpt_arena_bytes, need);
+      if (rc == MI_OK) {
+        char* a = h->bpt_arena;
+        auto take = [&](size_t bytes) { char* r = a; a += (bytes + 255) / 256 * 256; return r; };
+        w.lslab = reinterpret_cast<float4*>(take(slab)); w.eslab = reinterpret_cast<float4*>(take(slab)); w.nslab = reinterpret_cast<float4*>(take(slab));
+        w.emission = reinterpret_cast<float4*>(take(size_t(lanes) * cap * 16));
+        w.info = reinterpret_cast<uint4*>(take(size_t(lanes) * 32));
+        w.item_offset = reinterpret_cast<uint32_t*>(take((size_t(lanes) + 1) * 4));
+        w.scan_tmp = reinterpret_cast<uint32_t*>(take((size_t(lanes) / 2048 + 2) * 4));
+      }
+    } else {
+      rc = ensure(reinterpret_cast<void**>(&h->bpt_slab), &h->bpt_slab_bytes, size_t(lanes) * cap * 112);
+      if (rc == MI_OK) w.slab = h->bpt_slab;
+    }
+    if (rc == MI_OK) break;
+    if (rc != MI_ERR_OUT_OF_MEMORY) return rc;
+    (void)hipGetLastError();  // clear the sticky out-of-memory error before the retry
+    if (cap > 16) cap = cap / 2 < 16 ? 16 : cap / 2;
+    else if (lanes > 256) lanes = (lanes / 2 + 255) / 256 * 256;
+    else return rc;
   }
   *lanes_per_launch = uint32_t(lanes);
   p.counters = h->d_counters;

@@ -146,3 +146,21 @@ def test_bpt_error_behaviour(cornell):
         pt.bpt_trace_paths(16, 16, np.array([[16, 0]], np.uint32), np.array([0], np.uint64))
     with pytest.raises(ma.MiError):
         pt.bpt_render_rgbn(16, 16, spp=1, camera_id=5)
+
+
+def test_bpt_rejects_images_wider_than_its_pixel_packing_and_survives_a_tiny_slab_budget(monkeypatch):
+    """The staged BPT packs a path's pixel as (y << 16) | x: wider / taller images are refused, not rendered into wrong pixels.  The vertex
+    slabs are sized from the memory that is free (40 %, at most 3 x 16 GB) and shrink on an allocation failure: with a budget of 1 MB
+    (MI_BPT_SLAB_MB) the frame still renders, identical per path (long sub-paths go through the slice path)."""
+    s = load_scene("CornellBoxDiffuse")
+    pt = ma.PathTracing(s, roulette=0.9, beta=2.0)
+    with pytest.raises(ma.MiError) as e:
+        pt.bpt_render_rgbn(70000, 1, spp=1, seed=1)
+    assert e.value.code == -5 and "65535" in str(e.value)
+    xy = np.stack(np.meshgrid(np.arange(24), np.arange(20)), -1).reshape(-1, 2).astype(np.uint32)
+    si = np.zeros(len(xy), np.uint64)
+    ref = pt.bpt_trace_paths(24, 20, xy, si, seed=5)
+    monkeypatch.setenv("MI_BPT_SLAB_MB", "1")
+    small = ma.PathTracing(s, roulette=0.9, beta=2.0).bpt_trace_paths(24, 20, xy, si, seed=5)
+    for a, b in zip(ref, small):
+        assert np.array_equal(a, b)

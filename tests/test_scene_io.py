@@ -114,6 +114,95 @@ def test_exr_round_trip_and_layout(tmp_path):
         ma.load_exr(p)
 
 
+def write_exr_like_openexr(path, img, compression, long_key=None):
+    """An EXR scan-line file written the way OpenEXR writes one — independent of master_amd/csrc/exr_io.cpp: channels B, G, R, denom (FLOAT),
+    increasing-y line order, `compression` in {0 none, 1 RLE, 2 ZIPS, 3 ZIP}: per chunk the lines' channel rows are split into even / odd
+    bytes, delta-predicted (d[i] = t[i] - t[i-1] + 128) and deflated (ZIP: 16 lines per chunk) or run-length coded."""
+    import struct
+    import zlib
+    h, w = img.shape[:2]
+    top_down = img[::-1]  # EXR line 0 = top; our row 0 = bottom
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(data)) + data
+    ch = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 2, 0, 0, 0, 0, 1, 1) for n in ("B", "G", "R", "denom")) + b"\0"
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    flags = 0x04 if long_key else 0
+    hdr = b"\x76\x2f\x31\x01" + bytes([2, flags, 0, 0])
+    hdr += attr("channels", "chlist", ch) + attr("compression", "compression", bytes([compression])) + attr("dataWindow", "box2i", box)
+    hdr += attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    if long_key:
+        hdr += attr(long_key, "string", b"value")
+    hdr += b"\0"
+    per = 16 if compression == 3 else 1
+    def rle(b):
+        out, i = bytearray(), 0
+        while i < len(b):
+            j = i
+            while j + 1 < len(b) and b[j + 1] == b[i] and j - i < 126:
+                j += 1
+            if j - i >= 2:
+                out += struct.pack("b", j - i) + b[i:i + 1]; i = j + 1
+            else:
+                k = i
+                while k < len(b) and k - i < 127 and not (k + 2 < len(b) and b[k] == b[k + 1] == b[k + 2]):
+                    k += 1
+                out += struct.pack("b", -(k - i)) + b[i:k]; i = k
+        return bytes(out)
+    chunks = []
+    for y0 in range(0, h, per):
+        raw = b"".join(top_down[y, :, c].astype("<f4").tobytes() for y in range(y0, min(h, y0 + per)) for c in (2, 1, 0, 3))
+        if compression == 0:
+            data = raw
+        else:
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]]).astype(np.int32)
+            d = t.copy(); d[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
+            enc = d.astype(np.uint8).tobytes()
+            data = rle(enc) if compression == 1 else zlib.compress(enc)
+            if len(data) >= len(raw):
+                data = raw  # OpenEXR stores a chunk raw when compression does not shrink it
+        chunks.append(struct.pack("<ii", y0, len(data)) + data)
+    table_at = len(hdr)
+    off, table = table_at + 8 * len(chunks), b""
+    for c in chunks:
+        table += struct.pack("<Q", off); off += len(c)
+    open(path, "wb").write(hdr + table + b"".join(chunks))
+
+
+@pytest.mark.parametrize("compression", [0, 1, 2, 3])
+def test_exr_reader_takes_the_compressions_the_reference_writes(tmp_path, compression):
+    """save_exr of the reference uses OpenEXR's default header = ZIP compression (exr.cpp:177-232): `master continue / merge / errors` inputs and
+    the baked reference images come in that form.  Files from an independent encoder (smooth and noisy content, a chunk that does not shrink and is
+    stored raw, a last partial ZIP block, a long attribute name) must load bit for bit."""
+    rng = np.random.default_rng(compression)
+    yy, xx = np.meshgrid(np.arange(37), np.arange(29), indexing="ij")
+    smooth = np.stack([np.sin(xx * 0.1) + yy * 0.01, np.full_like(xx, 2.5, dtype=np.float64), xx * 0.0, np.full_like(xx, 64.0, dtype=np.float64)], -1).astype(np.float32)
+    noisy = rng.uniform(0, 5, (37, 29, 4)).astype(np.float32)
+    for k, img in enumerate((smooth, noisy)):
+        p = str(tmp_path / ("c%d_%d.exr" % (compression, k)))
+        write_exr_like_openexr(p, img, compression, long_key="an_attribute_name_longer_than_thirty_one_bytes" if k else None)
+        assert np.array_equal(ma.load_exr(p).view(np.uint32), img.view(np.uint32))
+    raw = open(p, "rb").read()
+    for cut in (len(raw) // 3, len(raw) - 5):
+        open(p, "wb").write(raw[:cut])
+        with pytest.raises(ma.MiError):
+            ma.load_exr(p)
+
+
+def test_exr_writer_sets_the_long_name_flag(tmp_path):
+    img = np.ones((3, 4, 4), np.float32)
+    p = str(tmp_path / "l.exr")
+    key = "records[123456].frame_duration_of_the_frame"  # 43 bytes > 31
+    ma.save_exr(p, img, {key: "1.0", "short": "x"})
+    raw = open(p, "rb").read()
+    assert raw[5] & 0x04 and key.encode() + b"\0string\0" in raw and np.array_equal(ma.load_exr(p), img)
+    ma.save_exr(p, img, {"short": "x"})
+    assert not open(p, "rb").read()[5] & 0x04
+    with pytest.raises(ma.MiError):
+        ma.save_exr(p, img, {"k" * 300: "v"})
+
+
 def test_exr_vertical_flip(tmp_path):
     img = np.zeros((4, 3, 4), np.float32)
     img[0, :, 0] = 7.0  # our row 0 = bottom of the image
@@ -138,8 +227,11 @@ def test_host_parsers_survive_damaged_files(tmp_path):
     exe = str(tmp_path / "fuzz")
     src = [os.path.join(root, "tests", "tools", "fuzz_host_parsers.cpp")] + [os.path.join(root, "master_amd", "csrc", f) for f in ("scene_host.cpp", "blend_reader.cpp", "exr_io.cpp")]
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
-                    "-I", os.path.join(root, "include")] + src + ["-o", exe], check=True)
+                    "-I", os.path.join(root, "include")] + src + ["-o", exe, "-lz"], check=True)
     small = tmp_path / "in"; small.mkdir()
+    rng = np.random.default_rng(5)
+    for comp in (1, 2, 3):  # compressed EXR inputs from the independent encoder above: RLE, ZIPS, ZIP decoders under mutation
+        write_exr_like_openexr(str(small / ("z%d.exr" % comp)), rng.uniform(0, 2, (21, 19, 4)).astype(np.float32) * (comp != 2) + 1.0, comp)
     for n in ("CornellBoxDiffuse", "TestCase0", "TestCase10", "DoubleLight", "CornellBoxSpecular"):
         shutil.copy(os.path.join(root, "scenes", n + ".miscene"), small)
     dirs = [str(small)]

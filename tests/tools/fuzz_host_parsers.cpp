@@ -29,6 +29,18 @@ int main(int argc, char** argv) {
     while (dirent* e = readdir(dir)) {
       std::string n = e->d_name, p = std::string(argv[a]) + "/" + n;
       bool blend = n.size() > 6 && n.substr(n.size() - 6) == ".blend", ms = n.size() > 8 && n.substr(n.size() - 8) == ".miscene";
+      if (n.size() > 4 && n.substr(n.size() - 4) == ".exr") {  // compressed EXR files written by the test's own encoder: every decoder path under mutation
+        std::vector<unsigned char> d = slurp(p);
+        uint32_t w, h; float* px = nullptr;
+        if (mi_exr_load_rgbn(p.c_str(), &w, &h, &px) == 0) { mi_free(px); ++ok; } else ++bad;
+        for (int kk = 0; kk < n_exr / 4; ++kk) {
+          std::vector<unsigned char> m = d;
+          if (kk % 4 == 0) m.resize(rng() % m.size()); else for (int j = 0; j < 1 + kk % 7; ++j) m[rng() % m.size()] = (unsigned char)rng();
+          spit((work + "/m.exr").c_str(), m);
+          if (mi_exr_load_rgbn((work + "/m.exr").c_str(), &w, &h, &px) == 0) { volatile float s0 = px[0] + px[size_t(w) * h * 4 - 1]; (void)s0; mi_free(px); mut_ok++; } else mut_bad++;
+        }
+        continue;
+      }
       if (!blend && !ms) continue;
       std::vector<unsigned char> d = slurp(p);
       if (d.size() > (8u << 20)) continue;

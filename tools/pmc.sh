@@ -12,7 +12,7 @@ for set in \
   "FETCH_SIZE GRBM_GUI_ACTIVE" \
   "WRITE_SIZE GRBM_COUNT" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/pass$i" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || { echo "pass $i failed"; tail -3 "$OUT/pass$i.err"; }
+  rocprofv3 --pmc $set --output-format csv -d "$OUT/pass$i" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-hbm-workload "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || { echo "pass $i failed"; tail -3 "$OUT/pass$i.err"; }
 done
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections
@@ -21,7 +21,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = c
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
+        k = r["Kernel_Name"].split("(")[0][-80:]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         seen.add((k, r["Dispatch_Id"]))
     for k, _ in seen: calls[(k, f)] += 1

@@ -18,7 +18,13 @@ constexpr int kFeatPhong = 1, kFeatDelta = 2, kFeatPow = 4, kFeatLights = 8, kFe
 
 
 
-struct Hit { float t, u, v; uint32_t id, pos; };  // id = global triangle index, pos = Morton position
+// id = global triangle index, pos = Morton position.  While a closest-hit traversal runs, u and v hold Embree's UNdivided U and V and `den` their
+// divisor |den|; finish_hit() divides once per ray when the walk is over (the same two correctly rounded divisions the per-hit form made for every
+// accepted candidate — two IEEE divisions, ~24 instructions, taken out of a leaf body that runs for 2.8 lanes of 64 on average).
+struct Hit { float t, u, v; uint32_t id, pos; float den; };
+__device__ __forceinline__ void finish_hit(Hit& h) {
+  if (h.id != 0xFFFFFFFFu) { h.u = h.u / h.den; h.v = h.v / h.den; }
+}
 
 // SurfacePoint (SurfacePoint.hpp:37-63)
 struct Surf { f3 position, gnormal; m33 tangent; uint32_t material_id; };
@@ -58,7 +64,7 @@ MI_DEV bool tri_test(const float4* __restrict__ tris, uint32_t pos, f3 org, f3 d
     return false;
   }
   if (t < h.t || (t == h.t && id < h.id)) {
-    h.t = t; h.u = U / absden; h.v = V / absden; h.id = id; h.pos = pos;
+    h.t = t; h.u = U; h.v = V; h.den = absden; h.id = id; h.pos = pos;
     return true;
   }
   return false;
@@ -149,8 +155,8 @@ struct Visits { uint32_t nodes, tris; uint32_t* wave_iters; };  // wave_iters: L
 // NS = node stride in float4 units: 4 in HBM; the LDS copy pads nodes to 5 (80 B) so that lanes reading the same field of
 // different nodes spread over all 32 banks instead of 2 groups of 4 (64 B = 16 banks: every other node collides).
 template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, bool MASKED = true, class Stack = TravStack>
-MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 org, f3 dir,
-                     uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
+MI_DEV void traverse_raw(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 org, f3 dir,
+                         uint32_t ray_mask, Hit& h, Visits* vis) {
   const float4* nodes = sb + sv.off_nodes;
   const float4* tris = sb + sv.off_tris;
   if (sv.n_nodes == 0) {
@@ -414,7 +420,7 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
           if (mode == 2u) {
             if (t <= 1.0f) { atomicOr((unsigned int*)&d.occl[owner >> 5], 1u << (owner & 31u)); mode = 0u; pop = false; }
           } else if (t < h.t || (t == h.t && id < h.id)) {
-            h.t = t; h.u = U / absden; h.v = V / absden; h.id = id; h.pos = pos;
+            h.t = t; h.u = U; h.v = V; h.den = absden; h.id = id; h.pos = pos;
             tmax = t;
           }
         }
@@ -425,8 +431,16 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
       }
     }
   }
+  finish_hit(h);
   const uint32_t word = d.occl[lane >> 5];
   return (word >> (lane & 31u)) & 1u ? 0.0f : 1.0f;
+}
+
+template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, bool MASKED = true, class Stack = TravStack>
+MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 org, f3 dir,
+                     uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
+  traverse_raw<ANY, COUNT, QUANT, NS, MASKED>(sb, sv, stack, org, dir, ray_mask, h, vis);
+  if (!ANY) finish_hit(h);
 }
 
 // Scene::querySurface (Scene.cpp:80-126).  SS = shading-record stride in float4 units (8 in HBM, 9 in the padded LDS copy:

@@ -10,7 +10,7 @@
  * All loops produce the same dvec4 view bit for bit (checked here).  Prints one JSON line.
  *
  *   cc -O2 -std=c11 -I include examples/cadence.c -o cadence master_amd/libmi_pt.so -Wl,-rpath,$PWD/master_amd
- *   ./cadence scenes/CornellBoxDiffuse.miscene 512 512 400 [max_path] [frames per launch, default 4]
+ *   ./cadence scenes/CornellBoxDiffuse.miscene 512 512 400 [max_path] [frames per launch, default 8 up to 1 Mpixel, else 4]
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
   const unsigned width = (unsigned)atoi(argv[2]), height = (unsigned)atoi(argv[3]), frames = (unsigned)atoi(argv[4]);
   mi_pt_params params = {UINT64_MAX >> 1, 1.0f, 0.9f, 1.0f, 3};
   if (argc > 5 && atoll(argv[5]) > 0) params.max_path = (uint64_t)atoll(argv[5]);
-  unsigned batch = 4;
+  unsigned batch = (size_t)width * height <= (1u << 20) ? 8 : 4;  /* small frames: more of them per launch (a 512 x 512 frame is 1.3 rounds of waves) */
   if (argc > 6) batch = (unsigned)atoi(argv[6]);
   if (batch < 1 || batch > MI_PT_MAX_FRAMES_PER_BATCH) { fprintf(stderr, "batch must be in [1, %d]\n", MI_PT_MAX_FRAMES_PER_BATCH); return 2; }
   mi_scene* scene = NULL;

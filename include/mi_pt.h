@@ -225,7 +225,7 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
  * k holds exactly frames 0..k, so `--num-samples`, snapshots and `continue` (Application.cpp:226-229,245) see what they saw
  * before.  Random streams depend only on (seed, pixel, sample index): rendering ahead changes nothing in the image.
  * ---------------------------------------------------------------------------------------- */
-#define MI_PT_MAX_FRAMES_PER_BATCH 8
+#define MI_PT_MAX_FRAMES_PER_BATCH 16
 #define MI_PT_BATCHES_IN_FLIGHT 3
 int mi_pt_render_frames_async(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, mi_window win,
                               uint32_t n_frames, uint64_t seed, uint64_t first_sample, uint64_t* tickets /*[n_frames]*/);

@@ -9,8 +9,10 @@ namespace haste {
 
 namespace {
 
-constexpr unsigned kFramesPerBatch = 4;                             // frames of one launch (<= MI_PT_MAX_FRAMES_PER_BATCH)
 constexpr unsigned kBatchesAhead = MI_PT_BATCHES_IN_FLIGHT - 1;     // one slot is being consumed, the others render
+// frames of one launch (<= MI_PT_MAX_FRAMES_PER_BATCH): a 512 x 512 frame is 1.3 rounds of waves, so small frames go eight to a launch (0.131 ms per
+// frame against 0.152 with four); from a megapixel on the frame fills the chip by itself and the copy (16 B per pixel) is the limit
+unsigned frames_per_batch(size_t width, size_t height) { return width * height <= (size_t(1) << 20) ? 8u : 4u; }
 
 void check(int rc) {
   if (rc != MI_OK) throw std::runtime_error(mi_pt_last_error());  // runtime_assert.cpp:7-11 analogue
@@ -140,12 +142,13 @@ void GpuPathTracing::_drain() {
 }
 
 void GpuPathTracing::_render_ahead(const FrameKey& key, mi_window win) {
-  while (_frames.size() + kFramesPerBatch <= kBatchesAhead * kFramesPerBatch || _frames.empty()) {
+  const unsigned batch = frames_per_batch(key.width, key.height);
+  while (_frames.size() + batch <= kBatchesAhead * batch || _frames.empty()) {
     uint64_t tickets[MI_PT_MAX_FRAMES_PER_BATCH];
-    check(mi_pt_render_frames_async(_handle, uint32_t(key.camera), uint32_t(key.width), uint32_t(key.height), win, kFramesPerBatch, _seed,
+    check(mi_pt_render_frames_async(_handle, uint32_t(key.camera), uint32_t(key.width), uint32_t(key.height), win, batch, _seed,
                                     _next_sample, tickets));
-    for (unsigned f = 0; f < kFramesPerBatch; ++f) _frames.push_back(Frame{tickets[f], _next_sample + f});
-    _next_sample += kFramesPerBatch;
+    for (unsigned f = 0; f < batch; ++f) _frames.push_back(Frame{tickets[f], _next_sample + f});
+    _next_sample += batch;
   }
 }
 

@@ -84,7 +84,7 @@ class LaunchInfo(C.Structure):
                 ("frame_tiles_per_wave", C.c_uint32), ("frames", C.c_uint32), ("dynamic_fetch", C.c_uint32), ("reserved", C.c_uint32), ("partial_bytes", C.c_uint64), ("scene_bytes", C.c_uint64)]
 
 
-MAX_FRAMES_PER_BATCH, BATCHES_IN_FLIGHT = 8, 3  # MI_PT_MAX_FRAMES_PER_BATCH, MI_PT_BATCHES_IN_FLIGHT
+MAX_FRAMES_PER_BATCH, BATCHES_IN_FLIGHT = 16, 3  # MI_PT_MAX_FRAMES_PER_BATCH, MI_PT_BATCHES_IN_FLIGHT
 
 
 class SurfacePoint(C.Structure):
@@ -473,7 +473,7 @@ class PathTracing:
         _check(lib().mi_pt_last_launch(self._h, C.byref(li)))
         return li
 
-    def render_frames(self, view, n_frames, seed=0, camera_id=0, window=None, batch=4):
+    def render_frames(self, view, n_frames, seed=0, camera_id=0, window=None, batch=8):
         """The adapter's frame loop (integration/GpuPathTracing.cpp): `n_frames` calls of Technique::render at one sample per call, with
         batches of `batch` frames in flight — the next batches render while the host adds the frames of this one to the dvec4 view."""
         h, w = view.shape[:2]

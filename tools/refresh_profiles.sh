@@ -21,7 +21,7 @@ if [ "${1:-core}" = core ]; then
   python tools/time_to_rmse.py > $O/time_to_rmse_c2.json 2> $O/time_to_rmse.err
   cc -O2 -std=c11 -I include examples/cadence.c -o /tmp/cadence master_amd/libmi_pt.so -Wl,-rpath,$PWD/master_amd
   : > $O/cadence.jsonl
-  /tmp/cadence scenes/CornellBoxDiffuse.miscene 512 512 400 8 4 >> $O/cadence.jsonl 2>&1
+  /tmp/cadence scenes/CornellBoxDiffuse.miscene 512 512 480 8 8 >> $O/cadence.jsonl 2>&1
   /tmp/cadence scenes/CornellBoxDiffuse.miscene 1920 1080 96 8 4 >> $O/cadence.jsonl 2>&1
   /tmp/cadence scenes/LivingRoomLit.miscene 1920 1080 32 0 4 >> $O/cadence.jsonl 2>&1
 else

@@ -6,6 +6,8 @@
 * BASELINE configs[4] (C5) through its stand-in: the seeded `clutter` room at 3840x2160, pixel-tile shard of world size 8 —
   properties at full size plus windows inside one rank's tiles against the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -222,3 +224,28 @@ def test_dynamic_fetch_traversal_is_bit_identical_per_path(monkeypatch, name):
     monkeypatch.delenv("MI_PT_DYN")
     pt.render_rgbn(w, h, spp=2, seed=1)
     assert pt.last_launch().dynamic_fetch == (0 if pt.get_kernel() == ma.KERNEL_MEGA_LDS else 1)
+
+
+def test_bench_two_ranks_share_the_gpu_on_the_c5_shape(tmp_path):
+    """the N > 1 path of bench.py rehearsed on this box — two ranks (gloo, both on the one GPU), the C5 stand-in at 3840x2160 with the
+    pixel-tile shard: launcher contract (torch.distributed.run, 127.0.0.1), barrier + max-over-ranks timing, one JSON line on rank 0 that carries the
+    per-rank render / reduce times and the size of the reduce (126.6 MiB)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--scene", "clutter", "--width", "3840", "--height", "2160", "--spp", "2",
+           "--max-path", "0", "--shard", "tiles", "--backend", "gloo", "--share-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "Msamples/s"
+    pr = d["per_rank"]
+    assert len(pr["render_ms"]) == len(pr["reduce_ms"]) == len(pr["kernel_ms"]) == 2 and pr["reduce_bytes"] == 3840 * 2160 * 16
+    assert all(t > 0 for t in pr["render_ms"] + pr["reduce_ms"]) and "32x32 pixel tiles" in d["config"]["parallelism"]
+    assert "hbm_workload" not in d and "cpu_baseline" not in d and d["roofline"]["frac"] <= 1.0

@@ -190,6 +190,71 @@ def test_exr_reader_takes_the_compressions_the_reference_writes(tmp_path, compre
             ma.load_exr(p)
 
 
+def read_exr_like_openexr(path):
+    """An OpenEXR scan-line reader written from the file-format specification, independent of master_amd/csrc/exr_io.cpp (the image holds no OpenEXR
+    library): magic, version field, attribute list (name, type, size, value), the eight attributes every file must carry, the line-offset table,
+    then one chunk per scan line (y, byte count, channels in alphabetical order).  Returns (header dict, {channel: [H][W] float32 top-down})."""
+    import struct
+    d = open(path, "rb").read()
+    assert struct.unpack("<I", d[:4])[0] == 20000630, "magic"
+    version, flags = d[4], struct.unpack("<I", d[4:8])[0] >> 8
+    assert version == 2 and not flags & 0x2 and not flags & 0x10  # scan lines, single part
+    max_name = 255 if flags & 0x4 else 31
+    o, hdr = 8, {}
+    def cstr(o):
+        e = d.index(b"\0", o)
+        return d[o:e].decode(), e + 1
+    while d[o] != 0:
+        name, o = cstr(o); typ, o = cstr(o)
+        assert 1 <= len(name) <= max_name and 1 <= len(typ) <= max_name
+        size = struct.unpack("<i", d[o:o + 4])[0]; o += 4
+        hdr[name] = (typ, d[o:o + size]); o += size
+    o += 1
+    required = {"channels": "chlist", "compression": "compression", "dataWindow": "box2i", "displayWindow": "box2i", "lineOrder": "lineOrder",
+                "pixelAspectRatio": "float", "screenWindowCenter": "v2f", "screenWindowWidth": "float"}
+    for k, t in required.items():
+        assert k in hdr and hdr[k][0] == t, k
+    assert hdr["compression"][1] == b"\0" and hdr["lineOrder"][1] == b"\0"  # uncompressed, increasing y
+    x0, y0, x1, y1 = struct.unpack("<4i", hdr["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    chans, c = [], hdr["channels"][1]
+    p = 0
+    while c[p] != 0:
+        e = c.index(b"\0", p); nm = c[p:e].decode(); p = e + 1
+        ptype, plinear, xs, ys = struct.unpack("<iB3xii", c[p:p + 16]); p += 16
+        assert ptype == 2 and xs == 1 and ys == 1  # FLOAT, no subsampling
+        chans.append(nm)
+    assert chans == sorted(chans), "channels must be stored in alphabetical order"
+    offsets = struct.unpack("<%dQ" % h, d[o:o + 8 * h])
+    out = {nm: np.zeros((h, w), np.float32) for nm in chans}
+    for y in range(h):
+        off = offsets[y]
+        yy, nbytes = struct.unpack("<ii", d[off:off + 8])
+        assert yy == y0 + y and nbytes == w * 4 * len(chans)
+        row = np.frombuffer(d[off + 8:off + 8 + nbytes], "<f4").reshape(len(chans), w)
+        for k, nm in enumerate(chans):
+            out[nm][y] = row[k]
+    assert offsets[-1] + 8 + w * 4 * len(chans) == len(d)
+    return hdr, out
+
+
+def test_exr_writer_output_parses_by_the_file_format_specification(tmp_path):
+    """What mi_exr_save_rgbn writes, opened by an independent reader: required attributes and their types, channel list B, G, R,
+    denom as FLOAT, offset table, top-down rows, string metadata — the layout save_exr gives its files (exr.cpp:177-232)."""
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 9, (21, 34, 4)).astype(np.float32)
+    p = str(tmp_path / "w.exr")
+    ma.save_exr(p, img, {"technique": "PT", "statistics.num_samples": "17", "records[0].frame_duration_of_a_long_key_name": "0.5"})
+    hdr, ch = read_exr_like_openexr(p)
+    assert sorted(ch) == ["B", "G", "R", "denom"]
+    for k, nm in enumerate(("R", "G", "B", "denom")):
+        assert np.array_equal(ch[nm][::-1], img[..., k])  # EXR line 0 = top of the image, our row 0 = bottom
+    assert hdr["technique"] == ("string", b"PT") and hdr["statistics.num_samples"] == ("string", b"17")
+    assert hdr["records[0].frame_duration_of_a_long_key_name"] == ("string", b"0.5")
+    import struct
+    assert struct.unpack("<4i", hdr["displayWindow"][1]) == (0, 0, 33, 20) and struct.unpack("<f", hdr["pixelAspectRatio"][1])[0] == 1.0
+
+
 def test_exr_writer_sets_the_long_name_flag(tmp_path):
     img = np.ones((3, 4, 4), np.float32)
     p = str(tmp_path / "l.exr")

@@ -33,7 +33,8 @@ struct mi_pt_handle {
   uint4* qnodes = nullptr;
   uint4* qnodes4 = nullptr;
   bool float_nodes = false;        // HBM-resident kernels read the full-precision nodes: the 16-bit grid is too coarse for this scene
-  bool wide_nodes = false;         // HBM-resident kernels walk the wide nodes (scenes of >= 100 000 triangles; MI_PT_WIDE_NODES=0/1 overrides)
+  bool wide_nodes = false;         // the PT megakernel walks the wide nodes (every HBM-resident scene the 16-bit grid is fine enough for; MI_PT_WIDE_NODES=0/1 overrides)
+  bool wide_large = false;         // scenes of >= 100 000 triangles: the BPT kernels (two per-lane loops) walk the wide nodes only there
   bool stack_fits_lds = false;     // depth - 1 <= info.stack_entries: the binary walk needs no spill entries
   uint32_t stack_entries_hbm = 0;  // LDS rows of the traversal stack for kernels that read the scene from HBM (wide walk)
   mi::SceneView sv{};
@@ -342,8 +343,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     h->info.stack_entries = se;
     h->stack_fits_lds = need <= se;
     h->stack_entries_hbm = se4;
-    h->wide_nodes = nt >= 100000u;
-    if (const char* e = std::getenv("MI_PT_WIDE_NODES")) h->wide_nodes = std::atoi(e) != 0;
+    h->wide_nodes = nt >= 100000u;  // refined below: with the dynamic-fetch traversal the wide walk wins on every scene the 16-bit grid is fine enough for
     // Is the 16-bit grid fine enough for this scene?  Median triangle box, longest side in grid cells: far-away light quads
     // stretch the scene box of some of the reference's models (MetalRings: 400 units around 0.1-unit triangles, 16 cells per
     // triangle), and boxes rounded outward to whole cells then overlap their neighbours (16 instead of 9 triangle tests per ray).
@@ -361,7 +361,14 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
         cells[t] = m * coarsest;
       }
       std::nth_element(cells.begin(), cells.begin() + nt / 2, cells.end());
-      h->float_nodes = cells[nt / 2] < 24.0f && !h->wide_nodes;
+      // r02: a loop iteration of the dynamic-fetch traversal is a dependent fetch, and the wide walk needs half as many: LivingRoomLit +4 %, CornellBoxSpecular
+      // +3 %, TestCase8 (126 triangles) +14 % over the binary quantised walk (round 1, two loops: -3..-12 % below 100 000 triangles).  Scenes whose triangles
+      // are small against the grid keep the full-precision binary nodes (MetalRings: wide quantised -12 %).
+      const bool coarse = cells[nt / 2] < 24.0f;
+      h->wide_large = h->wide_nodes;
+      h->float_nodes = coarse && !h->wide_nodes;
+      if (!coarse) h->wide_nodes = true;
+      if (const char* e = std::getenv("MI_PT_WIDE_NODES")) { h->wide_nodes = h->wide_large = std::atoi(e) != 0; if (h->wide_nodes) h->float_nodes = false; else h->float_nodes = coarse; }
       if (const char* e = std::getenv("MI_PT_FLOAT_NODES")) h->float_nodes = std::atoi(e) != 0;
     }
   }
@@ -992,6 +999,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   if (rc) return rc;
   fill_pt(h, p);
   if (p.beta == 0.0f && p.features != 15u) p.features &= ~4u;  // FixedBeta<0> needs no pow either (Beta.hpp:24-41)
+  p.wide_nodes = h->float_nodes ? 2u : (h->wide_large ? 1u : 0u);  // the BPT kernels walk rays in per-lane loops: wide nodes pay from 100 000 triangles on (profiles/r01/ab_bvh4.txt)
   p.stack_entries = (bpt_staged() && use_lds_scene(h) && h->stack_fits_lds) ? h->info.stack_entries : h->stack_entries_hbm;  // staged kernels stage small scenes into LDS
   mi_camera_frame fr;
   rc = mi_camera_setup(&h->scene.cameras[camera_id], float(width) / float(height), &fr);

@@ -55,6 +55,9 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 #ifndef MI_WAVES_LDS
 #define MI_WAVES_LDS 6
 #endif
+#ifndef MI_DYN_W_HI
+#define MI_DYN_W_HI 6  // waves per SIMD the dynamic-fetch variants are compiled for where that many workgroups' LDS fit a CU (else 5)
+#endif
 #ifndef MI_DYN_TH
 #define MI_DYN_TH 8  // idle lanes that trigger a refill of the unified traversal loop
 #endif
@@ -536,7 +539,7 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
   void (*fn)(const RenderParams) = nullptr;
   const bool large = p.wide_nodes == 1u;
   const bool list = mode == 1;
-  const bool six = lds <= (160u * 1024u) / 6u;  // six workgroups of this LDS size fit a CU
+  const bool six = lds <= (160u * 1024u) / MI_DYN_W_HI;  // six workgroups of this LDS size fit a CU
   if (!lds_scene && p.wide_nodes == 2u && ((count || list) && !(p.dyn_traverse && p.lds_tables))) {  // full-precision 64-byte nodes from HBM: scenes whose triangles are small against the 16-bit grid
     if (count) fn = pt_megakernel<false, 0, true, MI_WAVES_HBM, 0>;
     else fn = pt_megakernel<false, 1, false, MI_WAVES_HBM, 0>;
@@ -563,7 +566,7 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
 #define MI_PICK4TD(M, W, Q, B) (f2 == 0 ? pt_megakernel<false, M, false, W, Q, (B) | 0, true, true, true> : f2 == 1 ? pt_megakernel<false, M, false, W, Q, (B) | 1, true, true, true> : \
                                 f2 == 2 ? pt_megakernel<false, M, false, W, Q, (B) | 2, true, true, true> : pt_megakernel<false, M, false, W, Q, (B) | 3, true, true, true>)
 #define MI_PICKTD(M, W, Q) (feat == kFeatAll ? pt_megakernel<false, M, false, W, Q, kFeatAll, true, true, true> : (feat & kFeatLights) ? MI_PICK4TD(M, W, Q, kFeatLights) : MI_PICK4TD(M, W, Q, 0))
-#define MI_PICK_HBM(W, Q) (p.lds_tables ? (p.dyn_traverse ? (six ? (mode == 2 ? MI_PICKTD(2, 6, Q) : MI_PICKTD(0, 6, Q)) : (mode == 2 ? MI_PICKTD(2, 5, Q) : MI_PICKTD(0, 5, Q))) : (mode == 2 ? MI_PICKT(2, W, Q) : MI_PICKT(0, W, Q))) : MI_PICK_MODE(false, W, Q, true))
+#define MI_PICK_HBM(W, Q) (p.lds_tables ? (p.dyn_traverse ? (six ? (mode == 2 ? MI_PICKTD(2, MI_DYN_W_HI, Q) : MI_PICKTD(0, MI_DYN_W_HI, Q)) : (mode == 2 ? MI_PICKTD(2, 5, Q) : MI_PICKTD(0, 5, Q))) : (mode == 2 ? MI_PICKT(2, W, Q) : MI_PICKT(0, W, Q))) : MI_PICK_MODE(false, W, Q, true))
     const int feat = (p.features & uint32_t(kFeatPow)) ? kFeatAll : int(p.features);  // a general beta is rare: only the general variant has pow
     const int f2 = feat & 3;
 #define MI_PICK4D(M, B) (f2 == 0 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 0, false, false, true> : f2 == 1 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 1, false, false, true> : \

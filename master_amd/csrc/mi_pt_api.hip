@@ -338,7 +338,9 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     uint32_t need4 = 3u * ((depth > 1 ? depth - 1u : 1u) + 1u) / 2u;
     need4 = (need4 + 3u) / 4u * 4u;
     if (need4 < need) need4 = need;
-    const uint32_t se4 = need4 < 12u ? need4 : 12u;
+    uint32_t lds_rows = 12u;  // LDS rows of the traversal stack (1 KB each per workgroup); deeper levels live in private memory
+    if (const char* e = std::getenv("MI_PT_STACK_ROWS")) { const int v = std::atoi(e); if (v >= 4 && v <= 12) lds_rows = uint32_t(v) / 4u * 4u; }
+    const uint32_t se4 = need4 < lds_rows ? need4 : lds_rows;
     if (need4 > se4 + 128u) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack (12 LDS + 128 spill entries)");
     h->info.stack_entries = se;
     h->stack_fits_lds = need <= se;

@@ -21,6 +21,13 @@ struct BptState {
   uint32_t* item_offset;   // [lanes + 1]: first connection item of every path (exclusive scan of the counts)
   uint32_t* scan_tmp;      // [ceil((lanes + 1) / 2048)]: tile totals of that scan
   float4* values;          // [items]: value of a connection | flags
+  // visibility stage (r02): the shadow rays of a launch's items as a compacted list, walked by persistent waves that refill idle lanes from it
+  float4* rays;            // [items][2]: (origin | 1 if the item casts a shadow ray), (direction | 0); t in (0, 1], mesh geometry only
+  uint8_t* occl;           // [items]: 1 = the item's shadow ray is blocked (written for items that cast one)
+  uint32_t* pool;          // [64] chunk cursors of the walking waves (bpt_visibility)
+  uint32_t dyn_vis;        // 1: bpt_items reads `occl` instead of walking the item's ray itself
+  uint32_t vis_th;         // idle lanes of a walking wave that trigger a refill from the ray list
+  uint32_t vis_wide;       // node records of the visibility walk: 1 = 64-byte wide quantised, 0 = 32-byte binary quantised (scenes read from HBM)
   float* eye;              // [frames][H][W][3] eye images (Technique::_eye_image)
   double* light;           // [frames][H][W][3] light images (Technique::_light_image)
   float sphere[4];         // scene bounding sphere (loader.cpp:408-432) for the emitters' bounded cosine sampling

@@ -38,6 +38,7 @@ struct Ctx {
   f3 sphere_c; float sphere_r;
   f3 sky_horizon, sky_zenith;
   uint32_t n_basic, n_shadow;
+  float pre_occ;  // bpt_connect<QN, true>: the visibility stage has walked this connection's shadow ray already (1 = visible)
 };
 
 MI_DEV float betaf(const Ctx& c, float x) {  // Beta.hpp:24-41
@@ -261,7 +262,7 @@ MI_DEV uint32_t trace_light(Ctx& c, Rng& g, const Slab& slab, bool& overflow) {
 }
 
 // BPTBase::_connect(light, eye) (BPT.cpp:192-224)
-template <int QN>
+template <int QN, bool PRE = false>
 MI_DEV f3 bpt_connect(Ctx& c, const LVert& light, const EVert& eye) {
   const f3 omega = normalize(eye.surface.position - light.surface.position);
   const BQuery lb = bpt_bsdf_query(c, light.surface, light.omega, omega);
@@ -270,7 +271,7 @@ MI_DEV f3 bpt_connect(Ctx& c, const LVert& light, const EVert& eye) {
   const float Ap = (light.A * betaf(c, lb.densityRev) + light.a * float(light.finite)) * betaf(c, e.bG * eb.densityRev);
   const float Cp = (eye.C * betaf(c, eb.density) + eye.c * float(eye.finite)) * betaf(c, e.fG * lb.density);
   const float weightInv = Ap + Cp + 1.0f;
-  const float occ = scene_occluded<QN>(c, eye.surface, light.surface);
+  const float occ = PRE ? c.pre_occ : scene_occluded<QN>(c, eye.surface, light.surface);
   f3 r = light.throughput * occ;
   r = r * lb.throughput; r = r * eye.throughput; r = r * eb.throughput;
   r = r * e.bCos; r = r * e.fG;
@@ -637,7 +638,227 @@ __global__ __launch_bounds__(256) void bpt_scan_add(uint32_t* __restrict__ data,
 }
 
 // ---- stage B: one lane per connection item ----
-template <bool LIST, int QN>
+// Which connection is item `item` of the launch?  Shared by bpt_rays and bpt_items.
+struct ItemRef {
+  uint32_t path, eye_k, lv_i;  // eye vertex (erec index), light-side record index
+  uint32_t type;               // 0 light vertex lrec[lv_i] -> camera erec[0] (a splat); 1 area NEE sample nrec[eye_k]; 2 directional NEE nrec[eye_k]; 3 light vertex lrec[lv_i]
+};
+MI_DEV ItemRef item_decode(const BptState& w, uint32_t item) {
+  ItemRef r;
+  // which path?  last path whose first item is <= item (paths without items share an offset with their successor)
+  uint32_t lo = 0, hi = w.lanes;
+  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (w.item_offset[mid] <= item) lo = mid; else hi = mid; }
+  r.path = lo;
+  const uint32_t local = item - w.item_offset[lo];
+  const uint4 inf = w.info[2 * size_t(lo)];
+  const uint32_t L = inf.x, E = inf.y;
+  if (local < L) { r.type = 0u; r.eye_k = 0u; r.lv_i = local; return r; }
+  const float4* erec = w.eslab + size_t(lo) * w.max_vertices * 7u;
+  // which eye vertex?  last one (k >= 1) whose first item is <= local
+  uint32_t klo = 1, khi = E;
+  while (khi - klo > 1u) { const uint32_t mid = (klo + khi) >> 1; if (__float_as_uint(erec[size_t(mid) * 7u + 5u].w) <= local) klo = mid; else khi = mid; }
+  const uint32_t kind = __float_as_uint(erec[size_t(klo) * 7u + 4u].w), item0 = __float_as_uint(erec[size_t(klo) * 7u + 5u].w);
+  const uint32_t idx = local - item0;
+  r.eye_k = klo;
+  if (kind != 0u && idx == 0u) { r.type = kind == 1u ? 1u : 2u; r.lv_i = klo; }
+  else { r.type = 3u; r.lv_i = idx - (kind ? 1u : 0u) + 1u; }
+  return r;
+}
+// pixel_position (Cameras.cpp:134-144) of a light vertex seen from the camera: false = outside the image (no splat, no shadow ray)
+MI_DEV bool splat_pixel(const RenderParams& p, const BptState& w, f3 eye_pos, f3 lv_pos, f3& omega, int& ix, int& iy) {
+  const m33 w2v = {F3(w.w2v[0], w.w2v[1], w.w2v[2]), F3(w.w2v[3], w.w2v[4], w.w2v[5]), F3(w.w2v[6], w.w2v[7], w.w2v[8])};
+  omega = normalize(lv_pos - eye_pos);
+  const f3 vd = mulmv(w2v, omega);
+  const float factor = p.focal_length_y / -vd.z;
+  const float x = vd.x * factor, y = vd.y * factor;
+  const float py = (y + 1.0f) * p.res_y * 0.5f;
+  const float px = (x + p.res_x * p.res_y_inv) * p.res_y * 0.5f;
+  if (!(0 <= px && px < p.res_x && 0 <= py && py < p.res_y)) return false;
+  ix = int(px); iy = int(py);
+  return true;
+}
+
+// ---- stage B1 (visibility, r02): the items' shadow rays as a list ----
+// Scene::occluded (Scene.cpp:151-180) of a connection needs only the two positions and geometric normals; everything else of _connect
+// waits for stage B3.  One lane per item, uniform work, no atomics (a compacted list needs one same-address atomic per wave: 55 000 per
+// launch serialise to 0.7 ms, as long as the tracing stage).
+__global__ __launch_bounds__(256) void bpt_rays(const RenderParams p, const BptState w, uint32_t item_count) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  bool has = false;
+  f3 ao = F3(0, 0, 0), ad = F3(0, 0, 0);
+  if (j < item_count) {
+    const ItemRef r = item_decode(w, j);
+    if (r.type != 2u) {
+      const float4* e = w.eslab + (size_t(r.path) * w.max_vertices + r.eye_k) * 7u;
+      const float4* l = (r.type == 1u ? w.nslab : w.lslab) + (size_t(r.path) * w.max_vertices + r.lv_i) * 7u;
+      const f3 opos = xyz(e[0]), ogn = xyz(e[1]), tpos = xyz(l[0]), tgn = xyz(l[1]);
+      has = true;
+      if (r.type == 0u) { f3 omega; int ix, iy; has = splat_pixel(p, w, opos, tpos, omega, ix, iy); }
+      // the ray of occluded() (pt_device.h): both ends nudged off their surfaces, t in (0, 1]
+      const f3 direction = tpos - opos;
+      ao = opos + (ogn * (dot(ogn, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+      const f3 at = tpos + (tgn * (dot(tgn, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+      ad = at - ao;
+    }
+  }
+  if (j < item_count) {  // ray j belongs to item j; w = 1 marks an item that casts a shadow ray (directional NEE and splats outside the image do not)
+    float4* o = w.rays + 2 * size_t(j);
+    o[0] = make_float4(ao.x, ao.y, ao.z, has ? 1.0f : 0.0f);
+    o[1] = make_float4(ad.x, ad.y, ad.z, 0.0f);
+  }
+}
+
+// ---- stage B2 (visibility, r02): persistent waves walk the ray list, idle lanes refill from it ----
+// One lane per item (round 1) pays the longest shadow ray of every wave: any-hit rays end after anything between one and a hundred
+// node visits, lane efficiency of the walk was 0.2-0.3.  Here a wave keeps walking: whenever BptState::vis_th lanes are idle they take
+// the next rays of the wave's chunk (chunks of kVisChunk rays come from one global cursor), so the wave is full until the list
+// is empty.  A ray's result goes to occl[item]; nothing else of the connection lives in this kernel (32 VGPRs of ray state).
+// Exit: the cursor passes the ray count -> `exhausted` is wave-uniform -> the wave leaves when its last ray ends.
+#ifndef MI_BPT_VIS_WAVES
+#define MI_BPT_VIS_WAVES 8
+#endif
+constexpr uint32_t kVisChunk = 128u, kVisCursors = 64u;
+template <int QN>
+__global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const RenderParams p, const BptState w, uint32_t n_rays, uint32_t n_cursors) {
+  extern __shared__ float4 smem[];
+  SceneView sv = p.sv;
+  const float4* sb = sv.blob;
+  uint32_t scene_f4 = 0;
+  if (QN == 0) { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); sb = smem; __syncthreads(); }
+  TravStackT<(QN != 0)> stack;
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
+  stack.cap = p.stack_entries;
+  constexpr int NS = QN == 0 ? 5 : 4;
+  const float4* nodes = sb + sv.off_nodes;
+  const float4* tris = sb + sv.off_tris;
+  const uint4* __restrict__ qn = sv.qnodes;
+  const uint4* __restrict__ q4 = sv.qnodes4;
+  const f3 glo = F3(sv.grid_lo[0], sv.grid_lo[1], sv.grid_lo[2]), gis = F3(sv.grid_inv_step[0], sv.grid_inv_step[1], sv.grid_inv_step[2]);
+  const uint32_t lane = threadIdx.x & 63u;
+  const int root = sv.n_nodes == 0 ? ~0 : 0;  // a one-triangle scene has no nodes: its "tree" is the leaf of triangle 0
+  // kVisCursors cursors instead of one: cursor r hands out the chunks r, r + K, r + 2K, ... (interleaved, so every cursor sees the whole
+  // list) to the workgroups with blockIdx % K == r; same-address atomics serialise at ~13 ns each
+  const uint32_t group = blockIdx.x % n_cursors;  // n_cursors = min(kVisCursors, workgroups): every cursor has a workgroup
+  uint32_t next = 0, end = 0;
+  bool exhausted = false, walking = false;
+  uint32_t item = 0;
+  f3 co = F3(0, 0, 0), cd = F3(0, 0, 0);
+  RayBox rb = make_raybox(co, F3(1, 1, 1));
+  int sp = 0, node = 0;
+  for (;;) {
+    const uint64_t busy = __ballot(walking);
+    const uint32_t n_idle = 64u - uint32_t(__popcll(busy));
+    if (!exhausted && (busy == 0ull || n_idle >= w.vis_th)) {
+      if (next == end) {
+        uint32_t k = 0;
+        if (lane == 0u) k = atomicAdd(&w.pool[group], 1u);
+        k = __shfl(k, 0, 64);
+        const uint64_t v = (uint64_t(k) * n_cursors + group) * kVisChunk;
+        if (v >= uint64_t(n_rays)) { exhausted = true; continue; }
+        next = uint32_t(v); end = n_rays - next < kVisChunk ? n_rays : next + kVisChunk;
+      }
+      const uint64_t idle = ~busy;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
+      const uint32_t avail = end - next, take = n_idle < avail ? n_idle : avail;
+      if (!walking && rank < take) {
+        const float4 a = w.rays[2 * size_t(next + rank)], b = w.rays[2 * size_t(next + rank) + 1];
+        if (a.w != 0.0f) {
+          co = xyz(a); cd = xyz(b); item = next + rank;
+          rb = QN ? make_raybox((co - glo) * gis, cd * gis) : make_raybox(co, cd);
+          sp = 0; node = root; walking = true;
+        }
+      }
+      next += take;
+      continue;
+    }
+    if (busy == 0ull) break;
+    if (walking) {
+      bool pop = false;
+      if (node >= 0) {
+        if (QN == 2) {
+          float t[4]; int l[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint4 a = q4[4 * node + k];
+            const f3 lo = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
+            const f3 hi = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
+            float tn;
+            const bool hk = box_test(lo, hi, rb, 1.0f, tn) && int(a.w) != kEmptyLink;
+            t[k] = hk ? tn : __builtin_inff();
+            l[k] = int(a.w);
+          }
+#define MI_CSWAP(a, b) do { const bool s_ = t[b] < t[a]; const float ta_ = s_ ? t[b] : t[a], tb_ = s_ ? t[a] : t[b]; \
+                            const int la_ = s_ ? l[b] : l[a], lb_ = s_ ? l[a] : l[b]; t[a] = ta_; t[b] = tb_; l[a] = la_; l[b] = lb_; } while (0)
+          MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); MI_CSWAP(1, 3); MI_CSWAP(1, 2);
+#undef MI_CSWAP
+          if (t[0] < __builtin_inff()) {
+            if (t[3] < __builtin_inff()) { stack.push(sp, uint32_t(l[3])); ++sp; }
+            if (t[2] < __builtin_inff()) { stack.push(sp, uint32_t(l[2])); ++sp; }
+            if (t[1] < __builtin_inff()) { stack.push(sp, uint32_t(l[1])); ++sp; }
+            node = l[0];
+          } else {
+            pop = true;
+          }
+        } else {
+          f3 lo0, hi0, lo1, hi1;
+          int l0, l1;
+          if (QN) {
+            const uint4 a = qn[2 * node], b = qn[2 * node + 1];
+            lo0 = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
+            hi0 = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
+            lo1 = F3(float(b.x & 0xFFFFu), float(b.x >> 16), float(b.y & 0xFFFFu));
+            hi1 = F3(float(b.y >> 16), float(b.z & 0xFFFFu), float(b.z >> 16));
+            l0 = int(a.w); l1 = int(b.w);
+          } else {
+            const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
+            lo0 = xyz(n0); hi0 = xyz(n1); lo1 = xyz(n2); hi1 = xyz(n3);
+            l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
+          }
+          float tn0, tn1;
+          const bool h0 = box_test(lo0, hi0, rb, 1.0f, tn0);
+          const bool h1 = box_test(lo1, hi1, rb, 1.0f, tn1);
+          if (h0 && h1) {
+            const bool sw = tn1 < tn0;
+            stack.push(sp, uint32_t(sw ? l0 : l1));
+            ++sp;
+            node = sw ? l1 : l0;
+          } else if (h0 || h1) {
+            node = h0 ? l0 : l1;
+          } else {
+            pop = true;
+          }
+        }
+      } else {
+        // rtcOccluded's single-ray Moeller-Trumbore (tri_test<true> in pt_device.h): mesh geometry only, first hit with t <= 1 ends the ray
+        const uint32_t pos = uint32_t(~node);
+        const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
+        const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
+        const uint32_t gmask = __float_as_uint(c.z);
+        const f3 ng = cross(e2, e1);
+        const f3 C = v0 - co;
+        const f3 R = cross(C, cd);
+        const float den = dot(ng, cd);
+        const float absden = fabsf(den);
+        const float sgn = den < 0.0f ? -1.0f : 1.0f;
+        const float U = dot(R, e2) * sgn;
+        const float V = dot(R, e1) * sgn;
+        const float T = dot(ng, C) * sgn;
+        pop = true;
+        if ((gmask & (1u << MI_ENTITY_MESH)) != 0u && den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absden && absden * 0.0f < T) {
+          const float t = T / absden;
+          if (t <= 1.0f) { w.occl[item] = 1u; walking = false; pop = false; }
+        }
+      }
+      if (pop) {
+        if (sp == 0) { w.occl[item] = 0u; walking = false; }
+        else { --sp; node = int(stack.pop(sp)); }
+      }
+    }
+  }
+}
+
+// ---- stage B3: one lane per connection item: both BSDF queries, MIS weight, value; PRE = visibility comes from stage B2 ----
+template <bool LIST, int QN, bool PRE>
 __global__ __launch_bounds__(kBlock, MI_BPT_ITEMS_WAVES) void bpt_items(const RenderParams p, const BptState w, uint32_t item_first, uint32_t item_count) {
   extern __shared__ float4 smem[];
   SceneView sv = p.sv;
@@ -650,38 +871,27 @@ __global__ __launch_bounds__(kBlock, MI_BPT_ITEMS_WAVES) void bpt_items(const Re
   const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= item_count) return;
   const uint32_t item = item_first + j;
-  // which path?  last path whose first item is <= item (paths without items share an offset with their successor)
-  uint32_t lo = 0, hi = w.lanes;
-  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (w.item_offset[mid] <= item) lo = mid; else hi = mid; }
-  const uint32_t path = lo;
-  const uint32_t local = item - w.item_offset[path];
-  const uint4 inf = w.info[2 * size_t(path)];
-  const uint32_t L = inf.x, E = inf.y;
+  const ItemRef ref = item_decode(w, item);
+  const uint32_t path = ref.path;
   const float4* lrec = w.lslab + size_t(path) * w.max_vertices * 7u;
   const float4* erec = w.eslab + size_t(path) * w.max_vertices * 7u;
   const float4* nrec = w.nslab + size_t(path) * w.max_vertices * 7u;
   Ctx c; ctx_init(c, p, w, &stack, sb, &sv);
+  if (PRE) c.pre_occ = w.occl[j] ? 0.0f : 1.0f;
   f3 value = F3(0, 0, 0); uint32_t flags = 0;  // bit 0: a shadow ray was cast, bit 1: a closest-hit ray was cast, bit 2: splat inside the image
-  if (local < L) {
-    // ---- _connect_eye (BPT.cpp:295-321): light vertex `local` to the camera ----
-    uint32_t kind, item0;
-    const EVert eye = rec_load_e(erec, kind, item0);
-    const LVert lv = rec_load_l(lrec + size_t(local) * 7u);
-    const m33 w2v = {F3(w.w2v[0], w.w2v[1], w.w2v[2]), F3(w.w2v[3], w.w2v[4], w.w2v[5]), F3(w.w2v[6], w.w2v[7], w.w2v[8])};
+  uint32_t kind, item0;
+  const EVert eye = rec_load_e(erec + size_t(ref.eye_k) * 7u, kind, item0);
+  if (ref.type == 0u) {
+    // ---- _connect_eye (BPT.cpp:295-321): light vertex `lv_i` to the camera ----
+    const LVert lv = rec_load_l(lrec + size_t(ref.lv_i) * 7u);
     const float focal_factor_y = p.focal_length_y * p.focal_length_y * 0.25f;
-    const f3 omega = normalize(lv.surface.position - eye.surface.position);
-    const f3 vd = mulmv(w2v, omega);
-    const float factor = p.focal_length_y / -vd.z;  // pixel_position (Cameras.cpp:134-144)
-    const float x = vd.x * factor, y = vd.y * factor;
-    const float py = (y + 1.0f) * p.res_y * 0.5f;
-    const float px = (x + p.res_x * p.res_y_inv) * p.res_y * 0.5f;
-    if (0 <= px && px < p.res_x && 0 <= py && py < p.res_y) {
-      const int ix = int(px), iy = int(py);
+    f3 omega; int ix = 0, iy = 0;
+    if (splat_pixel(p, w, eye.surface.position, lv.surface.position, omega, ix, iy)) {
       const f3 ln = lv.surface.tangent.c1, en = eye.surface.tangent.c1;
       const float normal_coefficient = fabsf(dot(omega, lv.surface.gnormal) * dot(lv.omega, ln) / (dot(omega, ln) * dot(lv.omega, lv.surface.gnormal)));
       const float ce = fabsf(dot(en, omega));
       const float focal_coefficient = 1.0f / (ce * ce * ce);
-      value = (bpt_connect<QN>(c, lv, eye) * focal_factor_y) * (normal_coefficient * focal_coefficient);
+      value = (bpt_connect<QN, PRE>(c, lv, eye) * focal_factor_y) * (normal_coefficient * focal_coefficient);
       flags = 1u | 4u;
       if (!LIST) {
         const uint32_t fl = w.info[2 * size_t(path) + 1].w >> 1;
@@ -689,21 +899,13 @@ __global__ __launch_bounds__(kBlock, MI_BPT_ITEMS_WAVES) void bpt_items(const Re
         atomicAdd(&l[0], double(value.x)); atomicAdd(&l[1], double(value.y)); atomicAdd(&l[2], double(value.z));
       }
     }
+  } else if (ref.type == 1u) {
+    const LVert lv = rec_load_l(nrec + size_t(ref.lv_i) * 7u); value = bpt_connect<QN, PRE>(c, lv, eye); flags = 1u;
+  } else if (ref.type == 2u) {
+    const LSample b = rec_load_dir(nrec + size_t(ref.lv_i) * 7u); value = bpt_connect_directional<QN>(c, eye, b); flags = 2u;
   } else {
-    // which eye vertex?  last one (k >= 1) whose first item is <= local
-    uint32_t klo = 1, khi = E;
-    while (khi - klo > 1u) { const uint32_t mid = (klo + khi) >> 1; if (__float_as_uint(erec[size_t(mid) * 7u + 5u].w) <= local) klo = mid; else khi = mid; }
-    uint32_t kind, item0;
-    const EVert eye = rec_load_e(erec + size_t(klo) * 7u, kind, item0);
-    const uint32_t idx = local - item0;
-    if (kind != 0u && idx == 0u) {
-      if (kind == 1u) { const LVert lv = rec_load_l(nrec + size_t(klo) * 7u); value = bpt_connect<QN>(c, lv, eye); flags = 1u; }
-      else { const LSample b = rec_load_dir(nrec + size_t(klo) * 7u); value = bpt_connect_directional<QN>(c, eye, b); flags = 2u; }
-    } else {
-      const uint32_t li = idx - (kind ? 1u : 0u) + 1u;
-      const LVert lv = rec_load_l(lrec + size_t(li) * 7u);
-      value = bpt_connect<QN>(c, lv, eye); flags = 1u;
-    }
+    const LVert lv = rec_load_l(lrec + size_t(ref.lv_i) * 7u);
+    value = bpt_connect<QN, PRE>(c, lv, eye); flags = 1u;
   }
   w.values[j] = make_float4(value.x, value.y, value.z, __uint_as_float(flags));
 }
@@ -898,12 +1100,31 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
 hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, bool lds_scene, uint32_t total_items, hipStream_t stream) {
   const size_t lds = size_t(p.stack_entries) * kBlock * 4 + (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0);
   if (total_items) {
+    hipError_t e;
+    if (w.dyn_vis) {
+      // visibility first: ray list (uniform), then persistent waves over it; 8 workgroups per CU at most are resident, later ones find the cursor at the end
+      e = hipMemsetAsync(w.pool, 0, kVisCursors * sizeof(uint32_t), stream);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(bpt_rays, dim3((total_items + 255u) / 256u), dim3(256), 0, stream, p, w, total_items);
+      void (*vis)(const RenderParams, const BptState, uint32_t, uint32_t) = lds_scene ? bpt_visibility<0> : (w.vis_wide ? bpt_visibility<2> : bpt_visibility<1>);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(vis), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (e != hipSuccess) return e;
+      const uint32_t want = (total_items + kVisChunk * kWavesPerBlock - 1u) / (kVisChunk * kWavesPerBlock), cap = 256u * 8u;
+      const uint32_t n_wg = want < cap ? want : cap;
+      hipLaunchKernelGGL(vis, dim3(n_wg), dim3(kBlock), lds, stream, p, w, total_items, n_wg < kVisCursors ? n_wg : kVisCursors);
+    }
     const dim3 grid((total_items + kBlock - 1) / kBlock), block(kBlock);
     void (*fn)(const RenderParams, const BptState, uint32_t, uint32_t) = nullptr;
-    if (lds_scene) fn = list ? bpt_items<true, 0> : bpt_items<false, 0>;
-    else if (p.wide_nodes == 1u) fn = list ? bpt_items<true, 2> : bpt_items<false, 2>;
-    else fn = list ? bpt_items<true, 1> : bpt_items<false, 1>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (w.dyn_vis) {
+      if (lds_scene) fn = list ? bpt_items<true, 0, true> : bpt_items<false, 0, true>;
+      else if (p.wide_nodes == 1u) fn = list ? bpt_items<true, 2, true> : bpt_items<false, 2, true>;
+      else fn = list ? bpt_items<true, 1, true> : bpt_items<false, 1, true>;
+    } else {
+      if (lds_scene) fn = list ? bpt_items<true, 0, false> : bpt_items<false, 0, false>;
+      else if (p.wide_nodes == 1u) fn = list ? bpt_items<true, 2, false> : bpt_items<false, 2, false>;
+      else fn = list ? bpt_items<true, 1, false> : bpt_items<false, 1, false>;
+    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, grid, block, lds, stream, p, w, 0u, total_items);
   }

@@ -113,6 +113,39 @@ def test_bpt_one_kernel_form_equals_staged_form(monkeypatch, name):
     np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)
 
 
+@pytest.mark.parametrize("name,wide", [("CornellBoxDiffuse", 0), ("CornellBoxSpecular", 0), ("CornellBoxSpecular", 1), ("LivingRoomLit", 0), ("LivingRoomLit", 1),
+                                       ("MirrorAndAreaLight", 0), ("TestCaseFurnace", 0), ("TestCase10", 1), ("TestCase29", 0)])
+def test_bpt_visibility_stage_is_bit_identical_per_path(monkeypatch, name, wide):
+    """r02: the connections' shadow rays as a list walked by persistent waves that refill idle lanes (bpt_rays / bpt_visibility), against
+    every item walking its own ray inside bpt_items.  Occlusion is a boolean of the ray: same values, same ray counts, same splat sums.
+    The stage is on by default only for large launches over scenes read from HBM; MI_BPT_DYN_VIS forces it (LDS-resident scenes, binary and
+    wide quantised nodes, sun lights = items without a shadow ray, splats outside the image)."""
+    s = load_scene(name)
+    pt = ma.PathTracing(s, beta=2.0)
+    xy, si = _paths(64, 48, 12000, 13)
+    monkeypatch.setenv("MI_BPT_DYN_VIS", "0")
+    a = pt.bpt_trace_paths(64, 48, xy, si, seed=5)
+    img_a = pt.bpt_render_rgbn(40, 30, spp=6, seed=2)
+    monkeypatch.setenv("MI_BPT_DYN_VIS", "1"); monkeypatch.setenv("MI_BPT_VIS_WIDE", str(wide))
+    b = pt.bpt_trace_paths(64, 48, xy, si, seed=5)
+    img_b = pt.bpt_render_rgbn(40, 30, spp=6, seed=2)
+    assert np.array_equal(a[2], b[2]) and _bits_equal(a[0], b[0]).all() and _bits_equal(a[1], b[1]).all()
+    assert np.array_equal(img_a[..., 3], img_b[..., 3])
+    np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)  # FP64 splat order is free
+    assert pt.last_stats.num_shadow_rays > 0 or name == "TestCase10"
+
+
+def test_bpt_visibility_stage_against_the_oracle(monkeypatch):
+    """the forced visibility stage against the CPU oracle directly (not only against the other device form)"""
+    monkeypatch.setenv("MI_BPT_DYN_VIS", "1")
+    s = load_scene("CornellBoxSpecular")
+    pt = ma.PathTracing(s, beta=2.0); orc = oracle.Oracle(s, beta=2.0)
+    xy, si = _paths(48, 32, 3000, 3)
+    a = pt.bpt_trace_paths(48, 32, xy, si, seed=9)
+    b = orc.bpt_trace_paths(48, 32, xy, si, seed=9)
+    assert np.array_equal(np.asarray(a[2]), np.asarray(b[2])) and _bits_equal(a[0], b[0]).all() and _bits_equal(a[1], b[1]).all()
+
+
 def test_bpt_long_paths_fall_back_to_the_reference_capacity(monkeypatch):
     """roulette 0.97 in a closed furnace: sub-paths of a hundred vertices.  With a tiny slab budget the first attempt overflows and
     the launch is redone in slices at 1024 vertices per sub-path (BPT.hpp:30) — same bits as the oracle."""

@@ -830,7 +830,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const
         }
       } else {
         // rtcOccluded's single-ray Moeller-Trumbore (tri_test<true> in pt_device.h): mesh geometry only, first hit with t <= 1 ends the ray
-        const uint32_t pos = uint32_t(~node);
+        const uint32_t pos = uint32_t(~node) & kLeafPosMask;  // bit 30 of ~node: pair leaf (layout.h), the triangle at pos + 1 is this lane's next iteration
         const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
         const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
         const uint32_t gmask = __float_as_uint(c.z);
@@ -848,6 +848,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const
           const float t = T / absden;
           if (t <= 1.0f) { w.occl[item] = 1u; walking = false; pop = false; }
         }
+        if ((uint32_t(node) & kLeafPairBit) == 0u && walking) { node = int((uint32_t(node) | kLeafPairBit) - 1u); pop = false; }
       }
       if (pop) {
         if (sp == 0) { w.occl[item] = 0u; walking = false; }

@@ -397,6 +397,55 @@ __global__ void k_depth(uint32_t n, const mi_bvh_node* __restrict__ nodes, const
   atomicMax(max_depth, d);
 }
 
+// ---- pair leaves (r02) ----
+// A child that is a node over two triangles A, B becomes one leaf link naming both, so that every walk tests the two triangles under their
+// common box without opening (and, for node records read from HBM, fetching) a node for them: C2 -1.4 of 8.2 node visits per closest-hit
+// ray.  To name two triangles with one link and no extra state in the walking lane, the intersection / shading streams are emitted in an
+// order in which B follows A: position' = Morton position, except that a partner moves up behind its A (a scan over 2 / 0 / 1 records per
+// position).  Leaf link = ~position' with bit 30 cleared for a pair (layout.h).  Hits do not depend on any of this ((t, id) minimum /
+// boolean); `plain` keeps the builder's links in Morton positions for mi_pt_bvh_download (the oracle's tree), sorted_tri stays Morton order.
+__global__ void k_plain_links(uint32_t n_nodes, const mi_bvh_node* __restrict__ nodes, int2* __restrict__ plain) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n_nodes) plain[i] = make_int2(nodes[i].link0, nodes[i].link1);
+}
+__global__ void k_pair_init(uint32_t nt, uint32_t* __restrict__ emits, uint32_t* __restrict__ a_of) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i <= nt) emits[i] = i < nt ? 1u : 0u;
+  if (i < nt) a_of[i] = 0xFFFFFFFFu;
+}
+__global__ void k_pair_mark(uint32_t n_nodes, const int2* __restrict__ plain, uint32_t* __restrict__ emits, uint32_t* __restrict__ a_of) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_nodes) return;
+  const int l[2] = {plain[i].x, plain[i].y};
+  for (int c = 0; c < 2; ++c) {
+    if (l[c] < 0) continue;
+    const int2 ch = plain[l[c]];
+    if (ch.x >= 0 || ch.y >= 0) continue;
+    const uint32_t pa = uint32_t(~ch.x), pb = uint32_t(~ch.y);  // a leaf has one parent: one writer per position
+    emits[pa] = 2u; emits[pb] = 0u; a_of[pb] = pa;
+  }
+}
+__global__ void k_pair_order(uint32_t nt, const uint32_t* __restrict__ sorted_tri, const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ a_of,
+                             uint32_t* __restrict__ perm, uint32_t* __restrict__ sorted2) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= nt) return;
+  const uint32_t a = a_of[i];
+  const uint32_t q = a != 0xFFFFFFFFu ? prefix[a] + 1u : prefix[i];
+  perm[i] = q;
+  sorted2[q] = sorted_tri[i];
+}
+__global__ void k_pair_relink(uint32_t n_nodes, mi_bvh_node* __restrict__ nodes, const int2* __restrict__ plain, const uint32_t* __restrict__ perm) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_nodes) return;
+  int l[2] = {plain[i].x, plain[i].y};
+  for (int c = 0; c < 2; ++c) {
+    if (l[c] < 0) { l[c] = int(~perm[uint32_t(~l[c])]); continue; }
+    const int2 ch = plain[l[c]];
+    if (ch.x < 0 && ch.y < 0) l[c] = int(~(perm[uint32_t(~ch.x)] | kLeafPairBit));
+  }
+  nodes[i].link0 = l[0]; nodes[i].link1 = l[1];
+}
+
 __global__ void k_emit(uint32_t n, const uint32_t* __restrict__ sorted_tri, const float* __restrict__ pos, const float* __restrict__ tan,
                        const uint32_t* __restrict__ idx, const uint32_t* __restrict__ tri_material, float4* __restrict__ tri_isect,
                        float4* __restrict__ tri_shade) {
@@ -504,11 +553,12 @@ __global__ void k_collapse4(uint32_t n_nodes, const mi_bvh_node* __restrict__ no
 // builder: 1 = PLOC (default), 0 = Karras LBVH.
 hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* tan, const uint32_t* idx, const uint32_t* tri_material,
                      mi_bvh_node* nodes, float4* tri_isect, float4* tri_shade, uint32_t* sorted_tri, uint64_t* morton,
-                     float scene_lo[3], float scene_hi[3], uint32_t* max_depth_out, float* build_ms, uint32_t* rounds_out, hipStream_t stream) {
+                     float scene_lo[3], float scene_hi[3], uint32_t* max_depth_out, float* build_ms, uint32_t* rounds_out, int2* plain_links,
+                     bool pairs, hipStream_t stream) {
   const uint32_t nblk_sort = (nt + kSortTile - 1) / kSortTile;
   const uint32_t g256 = (nt + 255) / 256;
   struct Scratch {
-    void* p[16]; int n = 0;
+    void* p[32]; int n = 0;
     hipError_t get(void** out, size_t bytes) { hipError_t e = hipMalloc(out, bytes ? bytes : 4); if (e == hipSuccess) p[n++] = *out; return e; }
     ~Scratch() { for (int i = 0; i < n; ++i) hipFree(p[i]); }
   } scratch;
@@ -584,7 +634,25 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
     }
   }
   hipLaunchKernelGGL(k_depth, dim3(g256), dim3(256), 0, stream, nt, nodes, leaf_parent, depth);
-  hipLaunchKernelGGL(k_emit, dim3(g256), dim3(256), 0, stream, nt, sorted_tri, pos, tan, idx, tri_material, tri_isect, tri_shade);
+  const uint32_t* emit_order = sorted_tri;
+  if (nt > 1) {
+    const uint32_t n_nodes = nt - 1, gn = (n_nodes + 255) / 256;
+    hipLaunchKernelGGL(k_plain_links, dim3(gn), dim3(256), 0, stream, n_nodes, nodes, plain_links);
+    if (pairs && nt < kLeafPairBit) {
+      uint32_t *emits = nullptr, *a_of = nullptr, *perm = nullptr, *sorted2 = nullptr;
+      BUILD_CHECK(scratch.get(reinterpret_cast<void**>(&emits), sizeof(uint32_t) * (size_t(nt) + 1)));
+      BUILD_CHECK(scratch.get(reinterpret_cast<void**>(&a_of), sizeof(uint32_t) * size_t(nt)));
+      BUILD_CHECK(scratch.get(reinterpret_cast<void**>(&perm), sizeof(uint32_t) * size_t(nt)));
+      BUILD_CHECK(scratch.get(reinterpret_cast<void**>(&sorted2), sizeof(uint32_t) * size_t(nt)));
+      hipLaunchKernelGGL(k_pair_init, dim3((nt + 256) / 256), dim3(256), 0, stream, nt, emits, a_of);
+      hipLaunchKernelGGL(k_pair_mark, dim3(gn), dim3(256), 0, stream, n_nodes, plain_links, emits, a_of);
+      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, emits, nt + 1);
+      hipLaunchKernelGGL(k_pair_order, dim3(g256), dim3(256), 0, stream, nt, sorted_tri, emits, a_of, perm, sorted2);
+      hipLaunchKernelGGL(k_pair_relink, dim3(gn), dim3(256), 0, stream, n_nodes, nodes, plain_links, perm);
+      emit_order = sorted2;
+    }
+  }
+  hipLaunchKernelGGL(k_emit, dim3(g256), dim3(256), 0, stream, nt, emit_order, pos, tan, idx, tri_material, tri_isect, tri_shade);
   BUILD_CHECK(hipGetLastError());
   BUILD_CHECK(hipEventRecord(ev1, stream));
   uint32_t ord[8];

@@ -10,7 +10,8 @@ namespace mi {
 
 hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* tan, const uint32_t* idx, const uint32_t* tri_material,
                      mi_bvh_node* nodes, float4* tri_isect, float4* tri_shade, uint32_t* sorted_tri, uint64_t* morton,
-                     float scene_lo[3], float scene_hi[3], uint32_t* max_depth_out, float* build_ms, uint32_t* rounds_out, hipStream_t stream);
+                     float scene_lo[3], float scene_hi[3], uint32_t* max_depth_out, float* build_ms, uint32_t* rounds_out, int2* plain_links, bool pairs,
+                     hipStream_t stream);
 
 hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, uint4* qnodes4, const float lo[3], const float inv_step[3],
                           hipStream_t stream);

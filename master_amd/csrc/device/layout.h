@@ -19,6 +19,10 @@ constexpr int kBlock = 256;  // threads per workgroup of the path kernels; measu
 constexpr int kWavesPerBlock = kBlock / 64;
 
 
+// Leaf links.  A negative link is a leaf: ~link = position in the intersection / shading streams, with kLeafPairBit set when the triangle
+// at position + 1 is to be tested under the same box as well (pair leaves, bvh_build.hip).
+constexpr uint32_t kLeafPairBit = 0x40000000u, kLeafPosMask = 0x3FFFFFFFu;
+
 struct SceneView {
   const float4* blob;  // HBM
   uint32_t off_nodes, off_tris, off_shade, off_mats, off_lights, off_cdf;  // in float4 units

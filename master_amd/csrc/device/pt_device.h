@@ -203,8 +203,14 @@ MI_DEV void traverse_raw(const float4* __restrict__ sb, const SceneView& sv, Sta
         }
       } else {
         if (COUNT) { ++vis->tris; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[1], 1u); }
-        const bool hit = tri_test<ANY, MASKED>(tris, uint32_t(~node), org, dir, ray_mask, h);
+        const uint32_t lp = uint32_t(~node), pos = lp & kLeafPosMask;
+        const bool hit = tri_test<ANY, MASKED>(tris, pos, org, dir, ray_mask, h);
         if (ANY && hit) return;
+        if (lp & kLeafPairBit) {  // pair leaf: the next triangle of the stream lies under the same box
+          if (COUNT) ++vis->tris;
+          const bool hit_b = tri_test<ANY, MASKED>(tris, pos + 1u, org, dir, ray_mask, h);
+          if (ANY && hit_b) return;
+        }
       }
       if (sp == 0) return;
       --sp;
@@ -244,8 +250,14 @@ MI_DEV void traverse_raw(const float4* __restrict__ sb, const SceneView& sv, Sta
       }
     } else {
       if (COUNT) { ++vis->tris; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[1], 1u); }
-      const bool hit = tri_test<ANY, MASKED>(tris, uint32_t(~node), org, dir, ray_mask, h);
+      const uint32_t lp = uint32_t(~node), pos = lp & kLeafPosMask;
+      const bool hit = tri_test<ANY, MASKED>(tris, pos, org, dir, ray_mask, h);
       if (ANY && hit) return;
+      if (lp & kLeafPairBit) {  // pair leaf: the next triangle of the stream lies under the same box
+        if (COUNT) ++vis->tris;
+        const bool hit_b = tri_test<ANY, MASKED>(tris, pos + 1u, org, dir, ray_mask, h);
+        if (ANY && hit_b) return;
+      }
     }
     if (sp == 0) return;
     --sp;
@@ -400,7 +412,7 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
       } else {
         // Embree single-ray Moeller-Trumbore (tri_test above), both ray kinds: a closest-hit ray sees every geometry and keeps the (t, id)
         // minimum; a shadow ray sees mesh geometry only and ends at the first hit with t <= 1
-        const uint32_t pos = uint32_t(~node);
+        const uint32_t pos = uint32_t(~node) & kLeafPosMask;  // bit 30 of ~node: pair leaf, the triangle at pos + 1 is this lane's next iteration
         const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
         const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
         const uint32_t id = __float_as_uint(c.y), gmask = __float_as_uint(c.z);
@@ -420,10 +432,11 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
           if (mode == 2u) {
             if (t <= 1.0f) { atomicOr((unsigned int*)&d.occl[owner >> 5], 1u << (owner & 31u)); mode = 0u; pop = false; }
           } else if (t < h.t || (t == h.t && id < h.id)) {
-            h.t = t; h.u = U; h.v = V; h.den = absden; h.id = id; h.pos = pos;
+            h.t = t; h.u = U; h.v = V; h.den = absden; h.id = id; h.pos = uint32_t(~node) & kLeafPosMask;
             tmax = t;
           }
         }
+        if ((uint32_t(node) & kLeafPairBit) == 0u && mode != 0u) { node = int((uint32_t(node) | kLeafPairBit) - 1u); pop = false; }  // ~(pos + 1), a single leaf
       }
       if (pop) {
         if (sp == 0) mode = 0u;

@@ -32,6 +32,7 @@ struct mi_pt_handle {
   float4* blob = nullptr;
   uint4* qnodes = nullptr;
   uint4* qnodes4 = nullptr;
+  int2* plain_links = nullptr;    // the builder's links of every node in Morton positions (mi_pt_bvh_download); the blob's nodes carry pair leaves
   bool float_nodes = false;        // HBM-resident kernels read the full-precision nodes: the 16-bit grid is too coarse for this scene
   bool wide_nodes = false;         // the PT megakernel walks the wide nodes (every HBM-resident scene the 16-bit grid is fine enough for; MI_PT_WIDE_NODES=0/1 overrides)
   bool wide_large = false;         // scenes of >= 100 000 triangles: the BPT kernels (two per-lane loops) walk the wide nodes only there
@@ -310,9 +311,11 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     float build_ms = 0.0f; uint32_t depth = 1, rounds = 0;
     const char* bsel = std::getenv("MI_PT_BVH");  // "lbvh" selects the Karras builder (A/B and regression runs)
     const int builder = (bsel && std::strcmp(bsel, "lbvh") == 0) ? 0 : 1;
+    const char* pe = std::getenv("MI_PT_PAIRS");  // MI_PT_PAIRS=0: no pair leaves (A/B)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->plain_links), size_t(n_nodes ? n_nodes : 1) * sizeof(int2)));
     HIP_TRY(mi::build_bvh(builder, nt, d_pos, d_tan, d_idx, d_tm, reinterpret_cast<mi_bvh_node*>(h->blob + sv.off_nodes), h->blob + sv.off_tris,
                           h->blob + sv.off_shade, h->d_sorted_tri, h->d_morton, h->info.scene_lo, h->info.scene_hi, &depth, &build_ms,
-                          &rounds, h->stream));
+                          &rounds, h->plain_links, !(pe && std::atoi(pe) == 0), h->stream));
     h->info.n_triangles = nt; h->info.n_nodes = n_nodes; h->info.max_depth = depth; h->info.build_ms = build_ms;
     h->info.builder = uint32_t(builder); h->info.build_rounds = rounds;
     // quantised node copy on a 65536^3 grid over the scene box (used by the kernels that read the scene from HBM)
@@ -415,6 +418,7 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->blob) hipFree(h->blob);
   if (h->qnodes) hipFree(h->qnodes);
   if (h->qnodes4) hipFree(h->qnodes4);
+  if (h->plain_links) hipFree(h->plain_links);
   if (h->d_sorted_tri) hipFree(h->d_sorted_tri);
   if (h->d_morton) hipFree(h->d_morton);
   if (h->partial) hipFree(h->partial);
@@ -1200,7 +1204,12 @@ int mi_pt_bvh_download(mi_pt_handle* h, mi_bvh_node* nodes, uint32_t* sorted_tri
   if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_bvh_download: null handle");
   HIP_TRY(hipSetDevice(h->device));
   static_assert(sizeof(mi_bvh_node) == 64, "mi_bvh_node must be 4 float4");
-  if (nodes && h->sv.n_nodes) HIP_TRY(hipMemcpy(nodes, h->blob + h->sv.off_nodes, size_t(h->sv.n_nodes) * 64, hipMemcpyDeviceToHost));
+  if (nodes && h->sv.n_nodes) {
+    HIP_TRY(hipMemcpy(nodes, h->blob + h->sv.off_nodes, size_t(h->sv.n_nodes) * 64, hipMemcpyDeviceToHost));
+    std::vector<int32_t> plain(size_t(h->sv.n_nodes) * 2);  // the builder's links, Morton positions (the device copy carries pair leaves over re-ordered streams)
+    HIP_TRY(hipMemcpy(plain.data(), h->plain_links, plain.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < h->sv.n_nodes; ++i) { nodes[i].link0 = plain[2 * size_t(i)]; nodes[i].link1 = plain[2 * size_t(i) + 1]; }
+  }
   if (sorted_tri) HIP_TRY(hipMemcpy(sorted_tri, h->d_sorted_tri, size_t(h->sv.n_tris) * 4, hipMemcpyDeviceToHost));
   if (morton) HIP_TRY(hipMemcpy(morton, h->d_morton, size_t(h->sv.n_tris) * 8, hipMemcpyDeviceToHost));
   return MI_OK;

@@ -363,7 +363,10 @@ int mi_pt_bvh_info(mi_pt_handle* h, mi_bvh_info* out);
  * six section offsets and the total size (float4 units); blob may be NULL to query sizes only. */
 int mi_pt_blob_download(mi_pt_handle* h, uint32_t offsets_f4[7], float* blob, size_t capacity_f4);
 /* nodes: [n_nodes]; sorted_tri: [n_triangles] global triangle id at each sorted position;
- * morton: [n_triangles] 63-bit codes in sorted order.  Any pointer may be NULL. */
+ * morton: [n_triangles] 63-bit codes in sorted order.  Any pointer may be NULL.
+ * The links returned are the builder's (leaf = ~Morton position).  The device copy of the nodes (mi_pt_blob_download) carries pair leaves
+ * instead: a node over two triangles is replaced in its parent by one leaf link, positions refer to streams in which the partner follows
+ * its triangle, bit 30 of ~link marks the pair (master_amd/csrc/device/layout.h). */
 int mi_pt_bvh_download(mi_pt_handle* h, mi_bvh_node* nodes, uint32_t* sorted_tri,
                        uint64_t* morton);
 

@@ -860,7 +860,10 @@ __global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const
 
 // ---- stage B3: one lane per connection item: both BSDF queries, MIS weight, value; PRE = visibility comes from stage B2 ----
 template <bool LIST, int QN, bool PRE>
-__global__ __launch_bounds__(kBlock, MI_BPT_ITEMS_WAVES) void bpt_items(const RenderParams p, const BptState w, uint32_t item_first, uint32_t item_count) {
+#ifndef MI_BPT_ITEMS_PRE_WAVES
+#define MI_BPT_ITEMS_PRE_WAVES 4  // with the traversal gone (PRE) the kernel is uniform BSDF arithmetic over 224 B of vertices: registers before occupancy
+#endif
+__global__ __launch_bounds__(kBlock, PRE ? MI_BPT_ITEMS_PRE_WAVES : MI_BPT_ITEMS_WAVES) void bpt_items(const RenderParams p, const BptState w, uint32_t item_first, uint32_t item_count) {
   extern __shared__ float4 smem[];
   SceneView sv = p.sv;
   const float4* sb = sv.blob;

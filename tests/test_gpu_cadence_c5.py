@@ -249,3 +249,38 @@ def test_bench_two_ranks_share_the_gpu_on_the_c5_shape(tmp_path):
     assert len(pr["render_ms"]) == len(pr["reduce_ms"]) == len(pr["kernel_ms"]) == 2 and pr["reduce_bytes"] == 3840 * 2160 * 16
     assert all(t > 0 for t in pr["render_ms"] + pr["reduce_ms"]) and "32x32 pixel tiles" in d["config"]["parallelism"]
     assert "hbm_workload" not in d and "cpu_baseline" not in d and d["roofline"]["frac"] <= 1.0
+
+
+# ---- pair leaves (bvh_build.hip k_pair_*): a node over two triangles becomes one leaf link over re-ordered streams ----
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "TestCase8", "CornellBoxSpecular", "LivingRoomLit", "MetalRings", "soup3000", "atrium:120000"])
+def test_pair_leaves_are_bit_identical_per_path(monkeypatch, name):
+    """MI_PT_PAIRS=0 builds the round-1 tree.  With pair leaves the walks open fewer nodes and test both triangles of a pair — the hit is the (t, id)
+    minimum and occlusion a boolean either way: per-path radiance, ray counts, frames and BPT paths are the same bits (LDS-resident walk, float / binary
+    quantised / wide quantised records read from HBM, unified loop), and the tree a caller downloads is the builder's in both cases."""
+    if name.startswith("soup"):
+        s = sb.random_soup(int(name[4:]), seed=5)
+    elif name.startswith("atrium"):
+        s = sb.load(name)
+    else:
+        s = load_scene(name)
+    w, h, spp = 40, 32, 5
+    xy = np.stack(np.meshgrid(np.arange(w), np.arange(h)), -1).reshape(-1, 2).astype(np.uint32)
+    xy, si = np.tile(xy, (spp, 1)), np.repeat(np.arange(spp, dtype=np.uint64), w * h)
+    out = {}
+    for pairs in ("0", "1"):
+        monkeypatch.setenv("MI_PT_PAIRS", pairs)  # read when the handle is created
+        pt = ma.PathTracing(s, max_path=9, beta=2.0)
+        rad, cnt = pt.trace_paths(w, h, xy, si, seed=17)
+        frame = pt.render_rgbn(w, h, spp=1, seed=17, sample_offset=2)
+        bpt = pt.bpt_trace_paths(w, h, xy[:2000], si[:2000], seed=3)
+        nodes, order, morton = pt.bvh()
+        out[pairs] = (rad, cnt, frame, bpt, nodes, order, morton)
+    a, b = out["0"], out["1"]
+    assert np.isclose(a[0], b[0], rtol=0, atol=0, equal_nan=True).all() and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    assert np.array_equal(a[3][2], b[3][2])
+    for k in (0, 1):
+        assert np.array_equal(np.asarray(a[3][k]).view(np.uint32), np.asarray(b[3][k]).view(np.uint32))
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])  # the downloaded tree does not change
+    if len(a[4]) > 1:  # ... and there is something to pair: some node has two leaf children
+        assert ((a[4]["link0"] < 0) & (a[4]["link1"] < 0)).any()

@@ -236,6 +236,8 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
   const mi::SceneData& s = h->scene;
   const uint32_t nt = uint32_t(s.indices.size() / 3), nmat = uint32_t(s.materials.size()), nl = uint32_t(s.lights.size());
   const uint32_t n_nodes = nt > 1 ? nt - 1 : 0;
+  // leaf links are ~position with bit 30 as the pair flag (layout.h), blob offsets are 32-bit float4 indices (11 float4 per triangle + nodes)
+  if (s.indices.size() / 3 >= (1ull << 28)) return fail(MI_ERR_UNSUPPORTED, "scenes of 2^28 triangles or more are not supported (32-bit offsets into the scene blob)");
 
   // blob layout (float4 units)
   mi::SceneView sv{};

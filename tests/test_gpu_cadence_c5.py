@@ -284,3 +284,35 @@ def test_pair_leaves_are_bit_identical_per_path(monkeypatch, name):
     assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])  # the downloaded tree does not change
     if len(a[4]) > 1:  # ... and there is something to pair: some node has two leaf children
         assert ((a[4]["link0"] < 0) & (a[4]["link1"] < 0)).any()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 9, 17])
+def test_tiny_trees_with_pair_leaves_against_the_oracle(monkeypatch, n):
+    """n surface triangles + the two of the light quad: trees of two to nineteen leaves, where almost every node's child is a node over two triangles (a root
+    over two leaves is the one bottom node that has no parent to carry its pair link).  Closest hits, occlusion and per-path radiance against the oracle,
+    through the LDS-resident walk and — forced — the records read from HBM (float, binary quantised, wide quantised)."""
+    s = sb.random_soup(n, seed=100 + n, extent=1.5, size=0.8)
+    rng = np.random.default_rng(n)
+    o = rng.uniform(-2.5, 2.5, (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tg = rng.uniform(-2.5, 2.5, (20000, 3)).astype(np.float32)
+    orc = oracle.Oracle(s, max_path=6)
+    oh, ot, op = orc.intersect(o, d)
+    oo = orc.occluded(o, tg)
+    w, h, spp = 24, 16, 4
+    xy = np.stack(np.meshgrid(np.arange(w), np.arange(h)), -1).reshape(-1, 2).astype(np.uint32)
+    xy, si = np.tile(xy, (spp, 1)), np.repeat(np.arange(spp, dtype=np.uint64), w * h)
+    orad, ocnt = orc.trace_paths(w, h, xy, si, seed=9)
+    for kernel, env in ((ma.KERNEL_AUTO, {}), (ma.KERNEL_MEGA_GLOBAL, {}), (ma.KERNEL_MEGA_GLOBAL, {"MI_PT_WIDE_NODES": "1"}),
+                        (ma.KERNEL_MEGA_GLOBAL, {"MI_PT_WIDE_NODES": "0", "MI_PT_FLOAT_NODES": "1"}), (ma.KERNEL_WAVEFRONT, {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pt = ma.PathTracing(s, max_path=6)
+        pt.set_kernel(kernel)
+        gh, gt, gp = pt.intersect(o, d)
+        assert np.array_equal(gp, op) and np.array_equal(gt, ot) and gh.tobytes() == oh.tobytes(), (kernel, env)
+        assert np.array_equal(pt.occluded(o, tg), oo), (kernel, env)
+        rad, cnt = pt.trace_paths(w, h, xy, si, seed=9)
+        assert np.isclose(rad, orad, rtol=0, atol=0, equal_nan=True).all() and np.array_equal(cnt, ocnt), (kernel, env)
+        for k in env:
+            monkeypatch.delenv(k)

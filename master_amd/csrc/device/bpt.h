@@ -17,6 +17,8 @@ struct BptState {
   // staged form: path-major records (7 float4 per vertex), emission terms, per-path info, item offsets and values
   float4* lslab; float4* eslab; float4* nslab;   // [lanes][max_vertices][7]: light vertices, eye vertices, NEE samples of the eye vertices
   float4* emission;        // [lanes][max_vertices]: emission terms of the eye sub-path (rgb | index of the eye vertex they follow)
+  uint2* evinfo;           // [lanes][max_vertices]: (NEE kind, first item) of every eye vertex — what bpt_gather and the item decode need of an eye vertex, 8 B
+                           // instead of two words in two 128-byte lines of its 112-byte record (r02: 0.9 GB -> 28 MB per launch on the Cornell box)
   uint4* info;             // [lanes][2]: (L, E, items, emission terms), (closest-hit rays of the tracing stage, directional NEE, py<<16|px, frame<<1|ok)
   uint32_t* item_offset;   // [lanes + 1]: first connection item of every path (exclusive scan of the counts)
   uint32_t* scan_tmp;      // [ceil((lanes + 1) / 2048)]: tile totals of that scan

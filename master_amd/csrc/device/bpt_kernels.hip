@@ -509,6 +509,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_TRACE_WAVES) void bpt_trace(const Re
       float4* erec = w.eslab + size_t(i) * w.max_vertices * 7u;
       float4* nrec = w.nslab + size_t(i) * w.max_vertices * 7u;
       float4* em = w.emission + size_t(i) * w.max_vertices;  // emission terms (eye sub-path hits on emitters): as many as vertices
+      uint2* evi = w.evinfo + size_t(i) * w.max_vertices;
       if (!bpt_roulette(c, g)) {  // BPT.cpp:17-19
         // ---- _traceLight (BPT.cpp:121-190) ----
         if (!bpt_roulette(c, g)) {
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_TRACE_WAVES) void bpt_trace(const Re
           if (E >= w.max_vertices) { overflow = true; break; }
           if (at_camera) {
             rec_store_e(erec + size_t(E) * 7u, prev, 0u, 0u);  // items [0, L): the splats of _connect_eye
+            evi[E] = make_uint2(0u, 0u);
             n_items = L;
           } else {
             uint32_t kind = 0;
@@ -557,6 +559,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_TRACE_WAVES) void bpt_trace(const Re
               else { kind = 2; rec_store_dir(nrec + size_t(E) * 7u, b); ++n_dir; }
             }
             rec_store_e(erec + size_t(E) * 7u, prev, kind, n_items);
+            evi[E] = make_uint2(kind, n_items);
             n_items += (kind ? 1u : 0u) + (L > 1u ? L - 1u : 0u);
           }
           const uint32_t k = E;
@@ -653,11 +656,11 @@ MI_DEV ItemRef item_decode(const BptState& w, uint32_t item) {
   const uint4 inf = w.info[2 * size_t(lo)];
   const uint32_t L = inf.x, E = inf.y;
   if (local < L) { r.type = 0u; r.eye_k = 0u; r.lv_i = local; return r; }
-  const float4* erec = w.eslab + size_t(lo) * w.max_vertices * 7u;
+  const uint2* evi = w.evinfo + size_t(lo) * w.max_vertices;
   // which eye vertex?  last one (k >= 1) whose first item is <= local
   uint32_t klo = 1, khi = E;
-  while (khi - klo > 1u) { const uint32_t mid = (klo + khi) >> 1; if (__float_as_uint(erec[size_t(mid) * 7u + 5u].w) <= local) klo = mid; else khi = mid; }
-  const uint32_t kind = __float_as_uint(erec[size_t(klo) * 7u + 4u].w), item0 = __float_as_uint(erec[size_t(klo) * 7u + 5u].w);
+  while (khi - klo > 1u) { const uint32_t mid = (klo + khi) >> 1; if (evi[mid].y <= local) klo = mid; else khi = mid; }
+  const uint32_t kind = evi[klo].x, item0 = evi[klo].y;
   const uint32_t idx = local - item0;
   r.eye_k = klo;
   if (kind != 0u && idx == 0u) { r.type = kind == 1u ? 1u : 2u; r.lv_i = klo; }
@@ -917,14 +920,16 @@ __global__ __launch_bounds__(kBlock, PRE ? MI_BPT_ITEMS_PRE_WAVES : MI_BPT_ITEMS
 // ---- stage C: per path, the sums in the reference's order ----
 template <bool LIST>
 __global__ __launch_bounds__(256) void bpt_gather(const RenderParams p, const BptState w, uint32_t item_first) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  // grid-stride over the paths: the three ray / path counters are same-line atomics, which serialise at ~13 ns each — one set per WAVE of a
+  // one-path-per-lane grid (49 000 per launch) cost more than the sums themselves; one set per workgroup of a capped grid is 3 x <= 1024
+  __shared__ uint32_t red[3][4];
   uint32_t nb = 0, ns = 0, np = 0;
-  if (i < w.lanes) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < w.lanes; i += gridDim.x * 256u) {
     const uint4 inf = w.info[2 * size_t(i)], inf2 = w.info[2 * size_t(i) + 1];
     if (inf2.w & 1u) {
       const uint32_t L = inf.x, E = inf.y, n_em = inf.w;
       const float4* vals = w.values + (size_t(w.item_offset[i]) - item_first);
-      const float4* erec = w.eslab + size_t(i) * w.max_vertices * 7u;
+      const uint2* evi = w.evinfo + size_t(i) * w.max_vertices;
       const float4* em = w.emission + size_t(i) * w.max_vertices;  // emission terms (eye sub-path hits on emitters): as many as vertices
       f3 radiance = F3(0, 0, 0), splat_sum = F3(0, 0, 0);
       uint32_t n_splat = 0, shadow = 0, basic = inf2.x, m = 0;
@@ -934,7 +939,8 @@ __global__ __launch_bounds__(256) void bpt_gather(const RenderParams p, const Bp
       }
       for (uint32_t k = 0; k < E; ++k) {
         if (k >= 1u) {
-          const uint32_t kind = __float_as_uint(erec[size_t(k) * 7u + 4u].w), item0 = __float_as_uint(erec[size_t(k) * 7u + 5u].w);
+          const uint2 ev = evi[k];
+          const uint32_t kind = ev.x, item0 = ev.y;
           const uint32_t n_k = (kind ? 1u : 0u) + (L > 1u ? L - 1u : 0u);
           f3 local = F3(0, 0, 0);  // BPT.cpp:276: a vertex's connections are summed on their own, then added to the path's radiance
           for (uint32_t t = 0; t < n_k; ++t) {
@@ -946,7 +952,7 @@ __global__ __launch_bounds__(256) void bpt_gather(const RenderParams p, const Bp
         }
         while (m < n_em && __float_as_uint(em[m].w) == k) { radiance = radiance + F3(em[m].x, em[m].y, em[m].z); ++m; }
       }
-      nb = basic; ns = shadow; np = 1;
+      nb += basic; ns += shadow; np += 1;
       if (LIST) {
         const size_t item = size_t(w.first) + i;
         p.list_radiance[3 * item] = radiance.x; p.list_radiance[3 * item + 1] = radiance.y; p.list_radiance[3 * item + 2] = radiance.z;
@@ -960,10 +966,14 @@ __global__ __launch_bounds__(256) void bpt_gather(const RenderParams p, const Bp
     }
   }
   for (int k = 32; k > 0; k >>= 1) { nb += __shfl_xor(nb, k, 64); ns += __shfl_xor(ns, k, 64); np += __shfl_xor(np, k, 64); }
-  if ((threadIdx.x & 63u) == 0 && p.counters) {
-    if (nb) atomicAdd(&p.counters[0], (unsigned long long)nb);
-    if (ns) atomicAdd(&p.counters[1], (unsigned long long)ns);
-    if (np) atomicAdd(&p.counters[3], (unsigned long long)np);
+  if ((threadIdx.x & 63u) == 0) { red[0][threadIdx.x >> 6] = nb; red[1][threadIdx.x >> 6] = ns; red[2][threadIdx.x >> 6] = np; }
+  __syncthreads();
+  if (threadIdx.x == 0 && p.counters) {
+    const unsigned long long b = (unsigned long long)red[0][0] + red[0][1] + red[0][2] + red[0][3], sh = (unsigned long long)red[1][0] + red[1][1] + red[1][2] + red[1][3],
+                             pa = (unsigned long long)red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    if (b) atomicAdd(&p.counters[0], b);
+    if (sh) atomicAdd(&p.counters[1], sh);
+    if (pa) atomicAdd(&p.counters[3], pa);
   }
 }
 
@@ -1132,7 +1142,8 @@ hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, grid, block, lds, stream, p, w, 0u, total_items);
   }
-  const dim3 g2((w.lanes + 255u) / 256u);
+  const uint32_t gb = (w.lanes + 255u) / 256u;
+  const dim3 g2(gb < 1024u ? gb : 1024u);
   if (list) hipLaunchKernelGGL(bpt_gather<true>, g2, dim3(256), 0, stream, p, w, 0u);
   else hipLaunchKernelGGL(bpt_gather<false>, g2, dim3(256), 0, stream, p, w, 0u);
   return hipGetLastError();

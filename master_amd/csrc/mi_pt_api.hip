@@ -1052,13 +1052,14 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     w.max_vertices = uint32_t(cap);
     if (staged) {
       const size_t slab = size_t(lanes) * cap * 112;
-      const size_t need = 3 * slab + size_t(lanes) * (cap * 16 + 32 + 4 + 1) + 8192;
+      const size_t need = 3 * slab + size_t(lanes) * (cap * 24 + 32 + 4 + 1) + 8192;
       rc = ensure(reinterpret_cast<void**>(&h->bpt_arena), &h->bpt_arena_bytes, need);
       if (rc == MI_OK) {
         char* a = h->bpt_arena;
         auto take = [&](size_t bytes) { char* r = a; a += (bytes + 255) / 256 * 256; return r; };
         w.lslab = reinterpret_cast<float4*>(take(slab)); w.eslab = reinterpret_cast<float4*>(take(slab)); w.nslab = reinterpret_cast<float4*>(take(slab));
         w.emission = reinterpret_cast<float4*>(take(size_t(lanes) * cap * 16));
+        w.evinfo = reinterpret_cast<uint2*>(take(size_t(lanes) * cap * 8));
         w.info = reinterpret_cast<uint4*>(take(size_t(lanes) * 32));
         w.item_offset = reinterpret_cast<uint32_t*>(take((size_t(lanes) + 1) * 4));
         w.scan_tmp = reinterpret_cast<uint32_t*>(take((size_t(lanes) / 2048 + 2) * 4));

@@ -5,7 +5,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 import master_amd as ma
 from master_amd import scenegen as sb
-for n in (30, 50, 70, 90, 110, 140, 180):
+os.environ.setdefault("MI_PT_LDS_LIMIT_KB", "156")  # let the LDS kernel run beyond the product's 48 KB rule: the point is to find where it stops paying
+for n in (30, 70, 90, 110, 140, 180, 240, 320):
     s = sb.random_soup(n, seed=3)
     row = []
     for k in (ma.KERNEL_MEGA_LDS, ma.KERNEL_MEGA_GLOBAL):

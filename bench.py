@@ -19,7 +19,7 @@ Prints ONE JSON line on rank 0.  Its `roofline` block never shows a fraction of 
   * For a scene that is read from HBM/L2, `achieved` is SURVEY 8(d)'s algorithmic bytes per segment (visit counters of the
     instrumented kernel on the same workload) x the segments of one launch / the launch time.
 
-At N = 1 the line also carries `hbm_workload`: one HBM-resident configuration (BASELINE configs[3] through its stand-in,
+At N = 1 the line also carries `time_to_rmse` (the second half of BASELINE.json's metric, outside the timed region) and `hbm_workload`: one HBM-resident configuration (BASELINE configs[3] through its stand-in,
 the 269 k-triangle atrium at 1920x1080, 256 spp, unbounded paths) timed after the primary region with its own
 ms_per_step, algorithmic bytes and measured traffic.
 """
@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--no-hbm-workload", action="store_true", help="skip the HBM-resident second workload (N = 1 only)")
+    ap.add_argument("--no-time-to-rmse", action="store_true", help="skip the time-to-target-RMSE block (N = 1, default scene only)")
     ap.add_argument("--hbm-scene", default="atrium")
     ap.add_argument("--hbm-size", default="1920x1080x256", help="WxHxSPP of the HBM-resident workload (BASELINE configs[3] shape)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses N ranks on one GPU")
@@ -343,6 +344,11 @@ def main():
     del pt
     if rank == 0 and world == 1 and not args.no_hbm_workload:
         out["hbm_workload"] = hbm_workload(ma, torch, args, seed)
+    if rank == 0 and world == 1 and not args.no_time_to_rmse and not args.no_hbm_workload and args.scene == "CornellBoxDiffuse":
+        try:  # the second half of BASELINE.json's metric; never allowed to cost the line
+            out["time_to_rmse"] = time_to_rmse(ma, scene, args)
+        except Exception as e:  # noqa: BLE001
+            out["time_to_rmse"] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, args, args.cpu_budget)
@@ -351,6 +357,35 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def time_to_rmse(ma, scene, args, target=0.01, frame_spp=16, ref_spp=65536, max_spp=4096):
+    """BASELINE.json's second metric: wall time until the RMS error (ImageView.cpp:60-85) of the accumulating view against a high-spp image drops
+    below `target`, rendering `frame_spp` samples per Technique::render call and logging (clock_time, rms_error) per call like the reference's
+    record_t (Technique.cpp:61-76).  The reference EXRs are missing blobs, so the target image is this integrator's own at `ref_spp` (other seed,
+    disjoint samples); the time includes the per-call framebuffer download and the host-side RMS.  Outside the timed region of `value`."""
+    import numpy as np
+    w, h = args.width, args.height
+    pt = ma.PathTracing(scene, max_path=args.max_path)
+    ref = np.zeros((h, w, 4), np.float64)
+    for k in range(0, ref_spp, 4096):
+        ref += pt.render_rgbn(w, h, spp=min(4096, ref_spp - k), seed=999, sample_offset=k)
+    ref_rgb = (ref[..., :3] / ref[..., 3:]).astype(np.float32)
+    pt2 = ma.PathTracing(scene, max_path=args.max_path)
+    view = np.zeros((h, w, 4), np.float64)
+    pt2.render(view, seed=1, reference=ref_rgb, spp=frame_spp)  # warm-up call (first launch of a handle), then start over
+    pt2 = ma.PathTracing(scene, max_path=args.max_path)
+    view[:] = 0
+    t0 = time.perf_counter()
+    hit = None
+    while pt2.statistics().num_samples < max_spp:
+        rec = pt2.render(view, seed=1, reference=ref_rgb, spp=frame_spp)
+        if rec["rms_error"] <= target:
+            hit = (time.perf_counter() - t0, pt2.statistics().num_samples, float(rec["rms_error"]))
+            break
+    return {"target_rms": target, "seconds": hit[0] if hit else None, "spp_at_target": hit[1] if hit else None, "rms_at_target": hit[2] if hit else None,
+            "frame_spp": frame_spp, "reference": "%d spp of the same estimator (the reference's EXRs are not in the tree)" % ref_spp,
+            "includes": "per-call framebuffer download and host-side RMS (ImageView.cpp:60-85)"}
 
 
 def hbm_workload(ma, torch, args, seed):

@@ -425,6 +425,9 @@ void mi_free(void* p);
 /* rms_abs_errors (ImageView.cpp:60-85): image = rgbn sums ([h][w][4]), reference = [h][w][3]. */
 int mi_rms_abs_errors(const float* rgbn, const float* reference_rgb, uint32_t width,
                       uint32_t height, float* rms, float* abs_err);
+/* The same over the caller's dvec4 view itself (what ImageView.cpp:60-85 takes: image_view_t<dvec4>): view = [h][w][4] double sums. */
+int mi_rms_abs_errors_view(const double* view, const float* reference_rgb, uint32_t width,
+                           uint32_t height, float* rms, float* abs_err);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -405,4 +405,21 @@ int mi_rms_abs_errors(const float* rgbn, const float* ref, uint32_t w, uint32_t 
   return MI_OK;
 }
 
+int mi_rms_abs_errors_view(const double* view, const float* ref, uint32_t w, uint32_t h, float* rms, float* abs_err) {
+  if (!view || !ref || !rms || !abs_err) return mi::fail(MI_ERR_INVALID_ARGUMENT, "mi_rms_abs_errors_view: null argument");
+  float r = 0.0f, a = 0.0f;  // float accumulators in pixel order, as the reference's loop (ImageView.cpp:72-78)
+  for (size_t i = 0; i < size_t(w) * h; ++i) {
+    const double ww = view[4 * i + 3];
+    const float d0 = std::fabs(float(view[4 * i] / ww) - ref[3 * i]);
+    const float d1 = std::fabs(float(view[4 * i + 1] / ww) - ref[3 * i + 1]);
+    const float d2 = std::fabs(float(view[4 * i + 2] / ww) - ref[3 * i + 2]);
+    a += d0 + d1 + d2;
+    r += d0 * d0 + d1 * d1 + d2 * d2;
+  }
+  const float num = float(size_t(w) * h * 3);
+  *rms = std::sqrt(r / num);
+  *abs_err = a / num;
+  return MI_OK;
+}
+
 }  // extern "C"

@@ -259,6 +259,13 @@ def test_rms_abs_errors_definition():
     for fn in (ma.rms_abs_errors, oracle.rms_abs_errors):
         rms, ab = fn(rgbn, ref)
         assert rms == pytest.approx(math.sqrt((d ** 2).sum() / d.size), rel=1e-5) and ab == pytest.approx(d.sum() / d.size, rel=1e-5)
+    # the entry point that takes the dvec4 view itself (ImageView.cpp:60-85 takes image_view_t<dvec4>): same definition; equal bits when the view holds float values
+    rms_v, ab_v = ma.rms_abs_errors_view(rgbn.astype(np.float64), ref)
+    assert (rms_v, ab_v) == ma.rms_abs_errors(rgbn, ref)
+    view = rng.uniform(0.5, 2, (7, 5, 4)) * 1000.0  # double sums that are not floats
+    dv = np.abs((view[..., :3] / view[..., 3:]).astype(np.float32) - ref)
+    rms_v, ab_v = ma.rms_abs_errors_view(view, ref)
+    assert rms_v == pytest.approx(math.sqrt((dv.astype(np.float64) ** 2).sum() / dv.size), rel=1e-5) and ab_v == pytest.approx(dv.sum() / dv.size, rel=1e-5)
 
 
 def test_oracle_runs_the_whole_reference_corpus():

@@ -619,6 +619,14 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   uint64_t n_chunks = (100000 + n_tiles - 1) / n_tiles;
   const uint64_t max_chunks = spp >= 32 ? spp / 16 : 1;
   if (n_chunks > max_chunks) n_chunks = max_chunks;
+  // r02: a short render (Technique::render with a few samples per call) would leave the chip part empty — 16 spp at 512^2 is 4 096 waves for 6 144 slots,
+  // 2.6 ms = 0.16 ms per sample against 0.095 in a long launch.  Four samples per wave cost 9 % per sample (tools/spp_scaling.py) but fill it:
+  // below four rounds of waves the chunks go down to 4 samples.
+  if (n_chunks * n_tiles < 24576 && spp >= 8) {
+    const uint64_t want = (24576 + n_tiles - 1) / n_tiles, cap = spp / 4;
+    const uint64_t n2 = want < cap ? want : cap;
+    if (n2 > n_chunks) n_chunks = n2;
+  }
   const uint64_t mem_chunks = (2ull << 30) / (uint64_t(width) * height * 32ull);
   if (n_chunks > mem_chunks) n_chunks = mem_chunks;
   if (n_chunks < 1) n_chunks = 1;

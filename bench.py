@@ -19,7 +19,7 @@ Prints ONE JSON line on rank 0.  Its `roofline` block never shows a fraction of 
   * For a scene that is read from HBM/L2, `achieved` is SURVEY 8(d)'s algorithmic bytes per segment (visit counters of the
     instrumented kernel on the same workload) x the segments of one launch / the launch time.
 
-At N = 1 the line also carries `time_to_rmse` (the second half of BASELINE.json's metric, outside the timed region) and `hbm_workload`: one HBM-resident configuration (BASELINE configs[3] through its stand-in,
+At N = 1 the line also carries — with --time-to-rmse — `time_to_rmse` (the second half of BASELINE.json's metric, outside the timed region) and `hbm_workload`: one HBM-resident configuration (BASELINE configs[3] through its stand-in,
 the 269 k-triangle atrium at 1920x1080, 256 spp, unbounded paths) timed after the primary region with its own
 ms_per_step, algorithmic bytes and measured traffic.
 """
@@ -186,7 +186,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--no-hbm-workload", action="store_true", help="skip the HBM-resident second workload (N = 1 only)")
-    ap.add_argument("--no-time-to-rmse", action="store_true", help="skip the time-to-target-RMSE block (N = 1, default scene only)")
+    ap.add_argument("--time-to-rmse", action="store_true", help="add the time-to-target-RMSE block (N = 1, default scene).  Off by default: it launches the same "
+                    "kernel variant at other sample counts, which would mix into the rocprofv3 per-kernel average of this command")
     ap.add_argument("--hbm-scene", default="atrium")
     ap.add_argument("--hbm-size", default="1920x1080x256", help="WxHxSPP of the HBM-resident workload (BASELINE configs[3] shape)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses N ranks on one GPU")
@@ -344,7 +345,7 @@ def main():
     del pt
     if rank == 0 and world == 1 and not args.no_hbm_workload:
         out["hbm_workload"] = hbm_workload(ma, torch, args, seed)
-    if rank == 0 and world == 1 and not args.no_time_to_rmse and not args.no_hbm_workload and args.scene == "CornellBoxDiffuse":
+    if rank == 0 and world == 1 and args.time_to_rmse and args.scene == "CornellBoxDiffuse":
         try:  # the second half of BASELINE.json's metric; never allowed to cost the line
             out["time_to_rmse"] = time_to_rmse(ma, scene, args)
         except Exception as e:  # noqa: BLE001

@@ -16,7 +16,7 @@ if [ "${1:-core}" = core ]; then
   cp $O/pmc_atrium/summary.txt $O/pmc_summary_atrium.txt; cp $O/pmc_summary_atrium.txt profiles/$R/pmc_summary_atrium.txt
   python tools/pmc_to_traffic.py profiles/$R/pmc_summary_atrium.txt atrium_1920x1080x256_mp999 > $O/traffic_atrium.json
   cp profiles/traffic.json $O/traffic.json
-  python bench.py --steps 5 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err
+  python bench.py --steps 5 --warmup 1 --time-to-rmse > $O/bench_n1.json 2> $O/bench_n1.err
   python tests/tools/cpu_baseline_c1.py > $O/cpu_restatement_c1_c2.json 2> $O/cpu_restatement.err
   python tools/time_to_rmse.py > $O/time_to_rmse_c2.json 2> $O/time_to_rmse.err
   cc -O2 -std=c11 -I include examples/cadence.c -o /tmp/cadence master_amd/libmi_pt.so -Wl,-rpath,$PWD/master_amd

@@ -334,7 +334,7 @@ def main():
                            "unlimited" if args.max_path >= ma.PTRDIFF_MAX else args.max_path,
                            " (BASELINE configs[1])" if is_c2 else ""),
                        "kernel": {1: "pt_megakernel<LDS scene>", 2: "pt_megakernel<HBM scene>", 3: "wavefront pipeline (wf_extend / wf_shade / wf_shadow / wf_regen)"}[pt.get_kernel()],
-                       "launch": {"workgroups": li.n_blocks, "sample_chunks": li.n_chunks, "lds_bytes_per_workgroup": li.lds_bytes, "partial_sum_bytes": li.partial_bytes},
+                       "launch": {"workgroups": li.n_blocks, "sample_chunks": li.n_chunks, "lds_bytes_per_workgroup": li.lds_bytes, "partial_sum_bytes": li.partial_bytes, "flat_leaves": li.flat_leaves},
                        "parallelism": "%s sharded over %d GPU(s), %s all-reduce of [H][W][4] f32" % ("32x32 pixel tiles" if tiles else "samples", world, "RCCL" if args.backend == "nccl" else args.backend),
                        "Mpaths_per_s": paths / elapsed / 1e6, "Mrays_per_s": (segs + shadow) / elapsed / 1e6,
                        "denom_equals_spp": denom_ok},

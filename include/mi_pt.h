@@ -255,7 +255,7 @@ typedef struct mi_pt_launch_info {
   uint32_t frame_tiles_per_wave; /* > 0: frame mode (spp == 1): paths write the framebuffer directly, a wave owns this many 8x8 tiles */
   uint32_t frames;               /* frame mode: frames of the launch */
   uint32_t dynamic_fetch;        /* 1: closest-hit and shadow rays shared one traversal loop with dynamic fetch (scenes read from HBM) */
-  uint32_t reserved;
+  uint32_t flat_leaves;          /* > 0: the flat leaf list ran instead of the tree walk (LDS-resident scenes): leaf boxes per ray */
   uint64_t partial_bytes;   /* FP64 partial sums written by the path kernel and read by pt_finalize           */
   uint64_t scene_bytes;     /* scene blob (+ quantised node copies) resident in HBM                           */
 } mi_pt_launch_info;

@@ -81,7 +81,7 @@ class PtStats(C.Structure):
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_uint32), ("n_blocks", C.c_uint32), ("n_chunks", C.c_uint32), ("chunk_spp", C.c_uint32),
                 ("lds_bytes", C.c_uint32), ("wide_nodes", C.c_uint32), ("features", C.c_uint32), ("lds_tables", C.c_uint32),
-                ("frame_tiles_per_wave", C.c_uint32), ("frames", C.c_uint32), ("dynamic_fetch", C.c_uint32), ("reserved", C.c_uint32), ("partial_bytes", C.c_uint64), ("scene_bytes", C.c_uint64)]
+                ("frame_tiles_per_wave", C.c_uint32), ("frames", C.c_uint32), ("dynamic_fetch", C.c_uint32), ("flat_leaves", C.c_uint32), ("partial_bytes", C.c_uint64), ("scene_bytes", C.c_uint64)]
 
 
 MAX_FRAMES_PER_BATCH, BATCHES_IN_FLIGHT = 16, 3  # MI_PT_MAX_FRAMES_PER_BATCH, MI_PT_BATCHES_IN_FLIGHT

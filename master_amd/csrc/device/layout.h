@@ -23,6 +23,9 @@ constexpr int kWavesPerBlock = kBlock / 64;
 // at position + 1 is to be tested under the same box as well (pair leaves, bvh_build.hip).
 constexpr uint32_t kLeafPairBit = 0x40000000u, kLeafPosMask = 0x3FFFFFFFu;
 
+// Flat leaf list (traverse_flat, pt_device.h): at most kFlatMaxLeaves leaf links (one mask bit each); an LDS leaf record is kFlatLeafF4 float4.
+constexpr uint32_t kFlatMaxLeaves = 32u, kFlatLeafF4 = 7u;
+
 struct SceneView {
   const float4* blob;  // HBM
   uint32_t off_nodes, off_tris, off_shade, off_mats, off_lights, off_cdf;  // in float4 units
@@ -68,6 +71,9 @@ struct RenderParams {
   uint32_t features;       // kFeat* bits the scene and parameters need (pt_device.h): selects the kernel variant compiled without the rest
   uint32_t dyn_traverse;   // LDS-resident kernels: closest-hit and shadow rays share one traversal loop with dynamic fetch (traverse_dyn)
   uint32_t lds_tables;     // HBM-resident kernels: materials, lights and the light CDF are staged into LDS by every workgroup (they fit kLdsTablesMaxF4)
+  // LDS-resident kernels, flat leaf list (traverse_flat, pt_device.h): flat_k > 0 selects it.  flat_table: flat_k x { lo.xyz, hi.xyz, link, - } in global
+  // memory, the flat_k_mesh leaves that hold a mesh triangle first
+  const float* flat_table; uint32_t flat_k, flat_k_mesh;
   // sample range
   uint32_t spp, n_chunks, chunk_spp;
   uint64_t seed, sample_offset;

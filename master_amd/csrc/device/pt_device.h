@@ -449,6 +449,109 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
   return (word >> (lane & 31u)) & 1u ? 0.0f : 1.0f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Flat leaf list (LDS-resident scenes of at most kFlatMaxLeaves leaf links; r03).
+//
+// A tree walk over a 32-triangle scene is all divergence: a node body serves a third of the wave, a leaf body three lanes of 64
+// (profiles/r02/ab_c2_leaf_bodies.txt).  Here the wave runs ONE instruction stream over the K leaf boxes of the tree — the box of every
+// leaf link, pair leaves counting once — with the boxes as SCALAR operands (s_load from the leaf table in global memory through the
+// scalar cache: no LDS read, no bank conflict, no VGPR), every lane testing its own ray and keeping a K-bit mask of the boxes it enters.
+// Real path segments of the Cornell box enter 1.6 of its 16 leaf boxes on average (tests/lab/flat_lab.py).  Then each lane tests the
+// leaves of its mask, two triangles per leaf record, straight from LDS: no stack, no node records, no pop.  What is tested never
+// changes the answer — the closest hit is the (t, id) minimum, occlusion a boolean — so everything stays bit-identical to the tree walk.
+//
+// Leaf table in global memory (scalar loads): K x { c.xyz, e.xyz, link, - } (32 B), leaves that hold a mesh triangle first (a shadow
+// ray, mesh mask, tests only those: k_mesh), padded to a multiple of 4 entries.  LDS leaf record (7 float4): triangle A, triangle B, each { v0, e1, e2, ng = cross(e2, e1) }
+// (ng is the per-test cross product of tri_test, formed once at staging by the same function), then idA, idB with the entity tag in bits
+// 30-31.  A leaf of one triangle holds it twice (same id: never replaces itself).  Slot 2k + j also indexes the shading records.
+typedef __attribute__((address_space(4))) const float cfloat;
+
+MI_DEV uint32_t flat_scene_f4(const SceneView& sv, uint32_t K) { return kFlatLeafF4 * K + 18u * K + (sv.blob_f4 - sv.off_mats); }
+MI_DEV void stage_scene_flat(float4* __restrict__ smem, SceneView& sv, const float* __restrict__ table, uint32_t K, uint32_t tid) {
+  const uint32_t o_shade = kFlatLeafF4 * K, o_rest = o_shade + 18u * K;
+  for (uint32_t s = tid; s < 2u * K; s += kBlock) {
+    const uint32_t k = s >> 1, j = s & 1u, link = __float_as_uint(table[8u * k + 6u]);
+    const uint32_t pos = (link & kLeafPosMask) + ((link & kLeafPairBit) ? j : 0u);
+    const float4 a = sv.blob[sv.off_tris + 3u * pos], b = sv.blob[sv.off_tris + 3u * pos + 1u], c = sv.blob[sv.off_tris + 3u * pos + 2u];
+    const f3 ng = cross(F3(b.z, b.w, c.x), F3(a.w, b.x, b.y));
+    float4* rec = smem + kFlatLeafF4 * k + 3u * j;
+    rec[0] = a; rec[1] = b; rec[2] = make_float4(c.x, ng.x, ng.y, ng.z);
+    const uint32_t ent = uint32_t(__builtin_ctz(__float_as_uint(c.z) | 0x8u));
+    reinterpret_cast<uint32_t*>(smem + kFlatLeafF4 * k + 6u)[j] = __float_as_uint(c.y) | (ent << 30);
+    for (uint32_t q = 0; q < 8u; ++q) smem[o_shade + 9u * s + q] = sv.blob[sv.off_shade + 8u * pos + q];
+  }
+  for (uint32_t i = tid; i < sv.blob_f4 - sv.off_mats; i += kBlock) smem[o_rest + i] = sv.blob[sv.off_mats + i];
+  sv.off_lights = o_rest + (sv.off_lights - sv.off_mats); sv.off_cdf = o_rest + (sv.off_cdf - sv.off_mats);
+  sv.off_nodes = 0u; sv.off_tris = 0u; sv.off_shade = o_shade; sv.off_mats = o_rest;
+}
+
+// one triangle of a leaf record: tri_test with ng read instead of formed (same bits)
+template <bool ANY>
+MI_DEV bool flat_tri(const float4 a, const float4 b, const float4 c, uint32_t idw, uint32_t slot, f3 org, f3 dir, Hit& h) {
+  const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x), ng = F3(c.y, c.z, c.w);
+  const f3 C = v0 - org;
+  const f3 R = cross(C, dir);
+  const float den = dot(ng, dir);
+  const float absden = fabsf(den);
+  const float sgn = den < 0.0f ? -1.0f : 1.0f;
+  const float U = dot(R, e2) * sgn;
+  const float V = dot(R, e1) * sgn;
+  const float T = dot(ng, C) * sgn;
+  if (ANY && (idw >> 30) != uint32_t(MI_ENTITY_MESH)) return false;  // Scene.cpp:42,173: shadow rays see mesh geometry only
+  if (!(den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absden && absden * 0.0f < T)) return false;
+  const float t = T / absden;
+  const uint32_t id = idw & 0x3FFFFFFFu;
+  if (ANY) {
+    if (t <= h.t) { h.id = id; return true; }
+    return false;
+  }
+  if (t < h.t || (t == h.t && id < h.id)) {
+    h.t = t; h.u = U; h.v = V; h.den = absden; h.id = id; h.pos = slot;
+    return true;
+  }
+  return false;
+}
+
+// The box loop.  Table entry k = { c.xyz, e.xyz, link, - }: centre and half extent of the leaf box, the half extent rounded up and padded on the
+// host by 2^-20 of the largest coordinate of the scene (cameras included), which covers every rounding of the three fmas below and of v_rcp_f32 for
+// rays that start inside the scene's bounds (mi_pt_create: flat table).  Per axis  m = c * inv - org * inv,  tnear = m - e * |inv|,  tfar = m + e * |inv|:
+// three fmas instead of two fmas, a min and a max — min / max / cmp issue at half the fma rate on gfx950 (tools/micro/valu_rate.hip).  The test only
+// has to be conservative.  Entries are padded to a multiple of 4 with boxes nothing enters (e = -1e30); the loop runs downwards and shifts the
+// mask left, so bit k of the mask is entry k.
+// K4: groups of four entries to test (all of them for a closest-hit ray, those holding the mesh leaves for a shadow ray, whose mask is then cut to
+// keep_mask).  h.t = the ray's tfar on entry (closest-hit rays: infinity, the clamp compiles away).
+template <bool ANY, bool COUNT = false>
+MI_DEV void traverse_flat(const float4* __restrict__ leaves, cfloat* __restrict__ table, uint32_t K4, uint32_t keep_mask, f3 org, f3 dir, Hit& h, Visits* vis) {
+  const RayBox rb = make_raybox(org, dir);
+  const f3 ainv = F3(fabsf(rb.inv.x), fabsf(rb.inv.y), fabsf(rb.inv.z));
+  uint32_t mask = 0u;
+  for (uint32_t g = K4; g-- != 0u;) {  // wave-uniform: four boxes per trip, scalar operands
+    cfloat* t = table + 32u * g;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      const float mx = fmaf(t[8 * j], rb.inv.x, -rb.oi.x), my = fmaf(t[8 * j + 1], rb.inv.y, -rb.oi.y), mz = fmaf(t[8 * j + 2], rb.inv.z, -rb.oi.z);
+      const float ex = t[8 * j + 3], ey = t[8 * j + 4], ez = t[8 * j + 5];
+      const float tn = fmaxf(fmaxf(fmaxf(fmaf(-ex, ainv.x, mx), fmaf(-ey, ainv.y, my)), fmaf(-ez, ainv.z, mz)), 0.0f);
+      float tf = fminf(fminf(fmaf(ex, ainv.x, mx), fmaf(ey, ainv.y, my)), fmaf(ez, ainv.z, mz));
+      if (ANY) tf = fminf(tf, h.t);
+      mask = (mask << 1) | (tn <= tf ? 1u : 0u);
+    }
+  }
+  if (ANY) mask &= keep_mask;
+  if (COUNT) vis->nodes += 4u * K4;
+  while (mask != 0u) {
+    const uint32_t k = uint32_t(__builtin_ctz(mask));
+    mask &= mask - 1u;
+    const float4* r = leaves + kFlatLeafF4 * k;
+    const float4 a0 = r[0], a1 = r[1], a2 = r[2], b0 = r[3], b1 = r[4], b2 = r[5];
+    const uint2 ids = *reinterpret_cast<const uint2*>(r + 6);
+    if (COUNT) vis->tris += 2u;
+    const bool ha = flat_tri<ANY>(a0, a1, a2, ids.x, 2u * k, org, dir, h);
+    const bool hb = flat_tri<ANY>(b0, b1, b2, ids.y, 2u * k + 1u, org, dir, h);
+    if (ANY && (ha || hb)) return;
+  }
+}
+
 template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, bool MASKED = true, class Stack = TravStack>
 MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 org, f3 dir,
                      uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {

@@ -55,6 +55,9 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 #ifndef MI_WAVES_LDS
 #define MI_WAVES_LDS 6
 #endif
+#ifndef MI_WAVES_FLAT
+#define MI_WAVES_FLAT 6  // flat leaf list (LDS-resident scenes of <= kFlatMaxLeaves leaves)
+#endif
 #ifndef MI_DYN_W_HI
 #define MI_DYN_W_HI 6  // waves per SIMD the dynamic-fetch variants are compiled for where that many workgroups' LDS fit a CU (else 5)
 #endif
@@ -82,7 +85,8 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 // workgroup (LivingRoom: 65 materials = 3.2 KB), so the shading block's dependent reads (triangle -> material -> light) stop at the triangle.
 // DYN: closest-hit and shadow rays of a trip share one traversal loop with dynamic fetch (traverse_dyn, pt_device.h);
 // the shadow ray of vertex k is resolved at the start of trip k + 1.
-template <bool LDS_SCENE, int MODE, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true, bool TBL = false, bool DYN = false>
+// FLAT: the flat leaf list instead of the tree walk (traverse_flat, pt_device.h): no nodes in LDS, no traversal stack.
+template <bool LDS_SCENE, int MODE, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true, bool TBL = false, bool DYN = false, bool FLAT = false>
 __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParams p) {
   constexpr bool LIST = MODE == 1, FRAME = MODE == 2, IMAGE = MODE == 0;
   extern __shared__ float4 smem[];
@@ -93,10 +97,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
 
   // LDS-resident variant: padded copy of the scene blob (stage_scene_to_lds, pt_device.h)
   constexpr int NS = LDS_SCENE ? 5 : 4, SS = LDS_SCENE ? 9 : 8;
-  const uint32_t blob_f4 = LDS_SCENE ? lds_scene_f4(sv) : (TBL ? sv.blob_f4 - sv.off_mats : 0u);
+  const uint32_t blob_f4 = LDS_SCENE ? (FLAT ? flat_scene_f4(sv, p.flat_k) : lds_scene_f4(sv)) : (TBL ? sv.blob_f4 - sv.off_mats : 0u);
   const float4* sb = sv.blob;
   const float4* __restrict__ light0 = p.sv.blob + p.sv.off_lights;  // global copy of the first light record (one-light variants read it through scalar loads)
-  if (LDS_SCENE) { stage_scene_to_lds(smem, sv, tid); sb = smem; }
+  if (LDS_SCENE) { if (FLAT) stage_scene_flat(smem, sv, p.flat_table, p.flat_k, tid); else stage_scene_to_lds(smem, sv, tid); sb = smem; }
+  cfloat* flat_table = (cfloat*)p.flat_table;  // constant address space: wave-uniform reads become scalar loads
   // tb / tv: where the tables are read from — the LDS copy of the whole scene, the LDS copy of the tables alone, or the blob in HBM
   const float4* tb = sb;
   SceneView tv = sv;
@@ -280,7 +285,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
     if (alive) {
       // ---- Scene::intersect (Scene.cpp:182-203) ----
       const uint32_t steps0 = vis_c.nodes + vis_c.tris;
-      if (!DYN) traverse<false, COUNT, QN, NS, false>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);  // unmasked: PT's closest-hit rays see every geometry
+      if (FLAT) { traverse_flat<false, COUNT>(sb, flat_table, (p.flat_k + 3u) >> 2, 0xFFFFFFFFu, org, dir, h, &vis_c); finish_hit(h); }
+      else if (!DYN) traverse<false, COUNT, QN, NS, false>(sb, sv, stack, org, dir, 0xFFFFFFFFu, h, &vis_c);  // unmasked: PT's closest-hit rays see every geometry
       MI_STAMP(1);  // closest-hit traversal
       ++path_basic;
       if (COUNT && h.id != 0xFFFFFFFFu) ++n_hits;
@@ -362,7 +368,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
         } else if (pending) {
           Hit sh; sh.t = 1.0f; sh.u = sh.v = 0.0f; sh.id = 0xFFFFFFFFu; sh.pos = 0;
           const uint32_t s0 = vis_s.nodes + vis_s.tris;
-          traverse<true, COUNT, QN, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
+          if (FLAT) traverse_flat<true, COUNT>(sb, flat_table, (p.flat_k_mesh + 3u) >> 2, p.flat_k_mesh >= 32u ? 0xFFFFFFFFu : (1u << p.flat_k_mesh) - 1u, sray.org, sray.dir, sh, &vis_s);
+          else traverse<true, COUNT, QN, NS>(sb, sv, stack, sray.org, sray.dir, 1u << MI_ENTITY_MESH, sh, &vis_s);
           if (COUNT) steps_mine_s = vis_s.nodes + vis_s.tris - s0;
           radiance = radiance + nee * (sh.id != 0xFFFFFFFFu ? 0.f : 1.f);  // PT.cpp:41: radiance += _connect(...)
         }
@@ -529,7 +536,8 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
 
 // ---- host-callable launchers (declared in launch.h) ----
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
-  return (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : (p.lds_tables ? size_t(p.sv.blob_f4 - p.sv.off_mats) * 16 : 0)) +
+  return (lds_scene ? (p.flat_k ? size_t(kFlatLeafF4 * p.flat_k + 18u * p.flat_k + (p.sv.blob_f4 - p.sv.off_mats)) * 16 : size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16)
+                    : (p.lds_tables ? size_t(p.sv.blob_f4 - p.sv.off_mats) * 16 : 0)) +
          size_t(p.stack_entries) * kBlock * 4 + kWavesPerBlock * kAccBytesPerWave + (p.dyn_traverse ? kWavesPerBlock * kDynBytesPerWave : 0);
 }
 
@@ -547,6 +555,8 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
   if (count && p.dyn_traverse && !lds_scene && p.lds_tables)  // instrumented dynamic-fetch variants (5-wave budget)
     fn = p.wide_nodes == 2u ? pt_megakernel<false, 0, true, 5, 0, kFeatAll, true, true, true>
                             : (large ? pt_megakernel<false, 0, true, 5, 2, kFeatAll, true, true, true> : pt_megakernel<false, 0, true, 5, 1, kFeatAll, true, true, true>);
+  else if (count && lds_scene && p.flat_k) fn = pt_megakernel<true, 0, true, MI_WAVES_FLAT, 0, kFeatAll, false, false, false, true>;
+  else if (list && lds_scene && p.flat_k) fn = pt_megakernel<true, 1, false, MI_WAVES_FLAT, 0, kFeatAll, false, false, false, true>;
   else if (count && p.dyn_traverse && lds_scene && p.stack_in_lds) fn = pt_megakernel<true, 0, true, MI_WAVES_LDS, 0, kFeatAll, false, false, true>;
   else if (count) fn = lds_scene ? pt_megakernel<true, 0, true, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, 0, true, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, 0, true, MI_WAVES_HBM, 1>);
   else if (list && lds_scene && p.dyn_traverse && p.stack_in_lds) fn = pt_megakernel<true, 1, false, MI_WAVES_LDS, 0, kFeatAll, false, false, true>;  // per-path parity hook of the dynamic-fetch variant
@@ -572,6 +582,11 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
 #define MI_PICK4D(M, B) (f2 == 0 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 0, false, false, true> : f2 == 1 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 1, false, false, true> : \
                          f2 == 2 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 2, false, false, true> : pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 3, false, false, true>)
 #define MI_PICKD(M) (feat == kFeatAll ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, kFeatAll, false, false, true> : (feat & kFeatLights) ? MI_PICK4D(M, kFeatLights) : MI_PICK4D(M, 0))
+#define MI_PICK4F(M, B) (f2 == 0 ? pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, (B) | 0, false, false, false, true> : f2 == 1 ? pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, (B) | 1, false, false, false, true> : \
+                         f2 == 2 ? pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, (B) | 2, false, false, false, true> : pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, (B) | 3, false, false, false, true>)
+#define MI_PICKF(M) (feat == kFeatAll ? pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, kFeatAll, false, false, false, true> : (feat & kFeatLights) ? MI_PICK4F(M, kFeatLights) : MI_PICK4F(M, 0))
+    if (lds_scene && p.flat_k) fn = mode == 2 ? MI_PICKF(2) : MI_PICKF(0);  // flat leaf list
+    else
     if (lds_scene && p.dyn_traverse && p.stack_in_lds) fn = mode == 2 ? MI_PICKD(2) : MI_PICKD(0);  // unified traversal with dynamic fetch
     else
     if (lds_scene) fn = p.stack_in_lds ? MI_PICK_MODE(true, MI_WAVES_LDS, 0, false) : MI_PICK_MODE(true, MI_WAVES_LDS, 0, true);  // shallow tree: stack without the spill path
@@ -579,6 +594,8 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
     else if (large) fn = MI_PICK_HBM(MI_WAVES_HBM_LARGE, 2);
     else fn = MI_PICK_HBM(MI_WAVES_HBM, 1);
 #undef MI_PICK_HBM
+#undef MI_PICKF
+#undef MI_PICK4F
 #undef MI_PICKTD
 #undef MI_PICK4TD
 #undef MI_PICKD

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,7 @@ struct mi_pt_handle {
   float4* blob = nullptr;
   uint4* qnodes = nullptr;
   uint4* qnodes4 = nullptr;
+  float* flat_table = nullptr; uint32_t flat_k = 0, flat_k_mesh = 0;  // flat leaf list of small scenes (traverse_flat, pt_device.h): leaf boxes + links, mesh leaves first
   int2* plain_links = nullptr;    // the builder's links of every node in Morton positions (mi_pt_bvh_download); the blob's nodes carry pair leaves
   bool float_nodes = false;        // HBM-resident kernels read the full-precision nodes: the 16-bit grid is too coarse for this scene
   bool wide_nodes = false;         // the PT megakernel walks the wide nodes (every HBM-resident scene the 16-bit grid is fine enough for; MI_PT_WIDE_NODES=0/1 overrides)
@@ -83,6 +85,7 @@ struct mi_pt_handle {
 
 namespace {
 
+constexpr uint32_t kFlatLeavesDefault = 24;  // flat leaf list by default up to this many leaf links (the uniform box loop costs ~20 VALU per leaf and ray)
 constexpr size_t kLdsSceneLimit = 52 * 1024;  // LDS bytes per workgroup of the LDS-resident kernels (scene copy + stack + sums): 3 workgroups per CU (160 KB / 3, allocation granules);
                                               // r02, tests/tools/lds_limit.py: 114 triangles (51 KB) LDS 11 107 vs HBM 9 566 Msamples/s, 144 triangles (63 KB, 2 per CU) 7 763 vs 8 763
 
@@ -154,6 +157,13 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   p.sv = h->sv;
   p.wide_nodes = h->float_nodes ? 2u : (h->wide_nodes ? 1u : 0u);
   p.stack_entries = (use_lds_scene(h) && h->kernel_choice != MI_PT_KERNEL_WAVEFRONT) ? h->info.stack_entries : h->stack_entries_hbm;
+  {  // flat leaf list (r03): LDS-resident scenes of at most kFlatLeavesDefault leaf links; MI_PT_FLAT=0/1 overrides (1: up to kFlatMaxLeaves)
+    const char* f = std::getenv("MI_PT_FLAT");
+    const char* d = std::getenv("MI_PT_DYN");  // an explicit MI_PT_DYN=1 asks for the dynamic-fetch tree walk (A/B, parity tests)
+    const bool want = f ? std::atoi(f) != 0 : (h->flat_k <= kFlatLeavesDefault && !(d && std::atoi(d) != 0));
+    p.flat_table = h->flat_table; p.flat_k = 0; p.flat_k_mesh = 0;
+    if (want && h->flat_k && use_lds_scene(h) && h->kernel_choice != MI_PT_KERNEL_WAVEFRONT) { p.flat_k = h->flat_k; p.flat_k_mesh = h->flat_k_mesh; p.stack_entries = 0; }
+  }
   p.stack_in_lds = (h->stack_fits_lds && p.stack_entries == h->info.stack_entries) ? 1u : 0u;
   const uint64_t mp = h->params.max_path;
   // "Unlimited" (Options.hpp:34, PTRDIFF_MAX) is 2^20 edges on the device: with roulette < 1 a path that long has probability < e^-100, so
@@ -190,6 +200,7 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
     const bool want = d ? std::atoi(d) != 0 : !lds;
     if (lds) p.dyn_traverse = (want && h->sv.n_nodes >= 1u && h->stack_fits_lds) ? 1u : 0u;
     else p.dyn_traverse = (want && h->sv.n_nodes >= 1u && p.lds_tables) ? 1u : 0u;
+    if (p.flat_k) p.dyn_traverse = 0u;
   }
 }
 
@@ -334,6 +345,59 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     HIP_TRY(mi::quantize_nodes(n_nodes, reinterpret_cast<const mi_bvh_node*>(h->blob + sv.off_nodes), h->qnodes, h->qnodes4, h->sv.grid_lo, h->sv.grid_inv_step, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->sv.qnodes = h->qnodes; h->sv.qnodes4 = h->qnodes4;
+    // flat leaf list (small scenes): the box and the link of every leaf link of the tree, pair leaves counting once; the leaves that hold a
+    // mesh triangle come first (shadow rays test only those, Scene.cpp:42,173)
+    if (n_nodes >= 1u && n_nodes <= 2u * mi::kFlatMaxLeaves) {
+      std::vector<mi_bvh_node> nd(n_nodes);
+      std::vector<float4> ti(size_t(nt) * 3);
+      HIP_TRY(hipMemcpy(nd.data(), h->blob + sv.off_nodes, size_t(n_nodes) * sizeof(mi_bvh_node), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(ti.data(), h->blob + sv.off_tris, ti.size() * sizeof(float4), hipMemcpyDeviceToHost));
+      struct Leaf { float lo[3], hi[3]; uint32_t link; bool mesh; };
+      std::vector<Leaf> leaves;
+      auto entity_mask = [&](uint32_t pos) { uint32_t m; std::memcpy(&m, &ti[3 * size_t(pos) + 2].z, 4); return m; };
+      std::vector<int32_t> todo{0};  // walk from the root: the nodes a pair leaf replaced are still in the array, unreferenced
+      while (!todo.empty() && leaves.size() <= mi::kFlatMaxLeaves) {
+        const mi_bvh_node& n = nd[size_t(todo.back())]; todo.pop_back();
+        for (int c = 0; c < 2; ++c) {
+          const int32_t link = c ? n.link1 : n.link0;
+          if (link >= 0) { if (uint32_t(link) < n_nodes) todo.push_back(link); continue; }
+          Leaf l;
+          std::memcpy(l.lo, c ? n.lo1 : n.lo0, 12); std::memcpy(l.hi, c ? n.hi1 : n.hi0, 12);
+          l.link = uint32_t(~link);
+          const uint32_t pos = l.link & mi::kLeafPosMask;
+          uint32_t m = entity_mask(pos);
+          if (l.link & mi::kLeafPairBit) m |= entity_mask(pos + 1u);
+          l.mesh = (m & (1u << MI_ENTITY_MESH)) != 0u;
+          leaves.push_back(l);
+        }
+      }
+      if (leaves.size() <= mi::kFlatMaxLeaves) {
+        std::stable_partition(leaves.begin(), leaves.end(), [](const Leaf& l) { return l.mesh; });
+        // entry = centre + half extent of the box, the half extent rounded up and padded by 2^-20 of the largest coordinate a ray can start from
+        // or a box can have (scene box and cameras): covers the roundings of traverse_flat's three fmas per axis and of v_rcp_f32 (pt_device.h)
+        double amax = 0.0;
+        for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(double(h->info.scene_lo[a])), std::fabs(double(h->info.scene_hi[a]))));
+        for (const mi_camera& cam : s.cameras) for (int a = 0; a < 3; ++a) amax = std::max(amax, std::fabs(double(cam.position[a])));
+        const double pad = amax * 0x1p-20 + 1e-30;
+        const size_t k_pad = (leaves.size() + 3) / 4 * 4;
+        std::vector<float> table(k_pad * 8, 0.0f);
+        for (size_t k = leaves.size(); k < k_pad; ++k) table[8 * k + 3] = table[8 * k + 4] = table[8 * k + 5] = -1e30f;  // nothing enters a padding entry
+        uint32_t k_mesh = 0;
+        for (size_t k = 0; k < leaves.size(); ++k) {
+          for (int a = 0; a < 3; ++a) {
+            const float c = float(0.5 * (double(leaves[k].lo[a]) + double(leaves[k].hi[a])));
+            const double e = std::max(double(leaves[k].hi[a]) - double(c), double(c) - double(leaves[k].lo[a])) + pad;
+            float ef = float(e);
+            if (double(ef) < e) ef = std::nextafter(ef, std::numeric_limits<float>::infinity());
+            table[8 * k + a] = c; table[8 * k + 3 + a] = ef;
+          }
+          std::memcpy(&table[8 * k + 6], &leaves[k].link, 4);
+          if (leaves[k].mesh) ++k_mesh;
+        }
+        rc = upload(&h->flat_table, table.data(), table.size() * 4); if (rc) return rc;
+        h->flat_k = uint32_t(leaves.size()); h->flat_k_mesh = k_mesh;
+      }
+    }
     // a root-to-leaf path of `depth` nodes has depth - 1 internal nodes, each of which can leave at most one
     // far child pending: that is the stack's capacity (rounded up to 4; LDS per workgroup = 1 KB per entry)
     uint32_t need = (depth > 1 ? depth - 1u : 1u);
@@ -424,6 +488,7 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->qnodes) hipFree(h->qnodes);
   if (h->qnodes4) hipFree(h->qnodes4);
   if (h->plain_links) hipFree(h->plain_links);
+  if (h->flat_table) hipFree(h->flat_table);
   if (h->d_sorted_tri) hipFree(h->d_sorted_tri);
   if (h->d_morton) hipFree(h->d_morton);
   if (h->partial) hipFree(h->partial);
@@ -607,7 +672,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
     li.n_blocks = uint32_t(n_blocks); li.n_chunks = 1; li.chunk_spp = 1; li.frame_tiles_per_wave = tiles_per_wave; li.frames = n_frames;
     li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
-    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = p.dyn_traverse ? 1u : 0u;
+    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = p.dyn_traverse ? 1u : 0u; li.flat_leaves = p.flat_k;
     li.partial_bytes = 0;
     li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
     if (stats) return collect_stats(h, stream, stats, ev);
@@ -654,7 +719,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
     li.n_blocks = uint32_t(n_blocks); li.n_chunks = p.n_chunks; li.chunk_spp = p.chunk_spp;
     li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
-    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = p.dyn_traverse ? 1u : 0u;
+    li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = p.dyn_traverse ? 1u : 0u; li.flat_leaves = p.flat_k;
     li.partial_bytes = uint64_t(p.n_chunks) * win.w * win.h * 32ull;
     li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
   }
@@ -1033,6 +1098,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   if (p.beta == 0.0f && p.features != 15u) p.features &= ~4u;  // FixedBeta<0> needs no pow either (Beta.hpp:24-41)
   p.wide_nodes = h->float_nodes ? 2u : (h->wide_large ? 1u : 0u);  // the BPT kernels walk rays in per-lane loops: wide nodes pay from 100 000 triangles on (profiles/r01/ab_bvh4.txt)
   p.stack_entries = (bpt_staged() && use_lds_scene(h) && h->stack_fits_lds) ? h->info.stack_entries : h->stack_entries_hbm;  // staged kernels stage small scenes into LDS
+  p.flat_k = 0; p.flat_k_mesh = 0;  // the BPT kernels walk the tree
   mi_camera_frame fr;
   rc = mi_camera_setup(&h->scene.cameras[camera_id], float(width) / float(height), &fr);
   if (rc) return rc;

@@ -8,7 +8,8 @@ static unsigned char* g_log; static uint64_t g_log_n, g_log_cap;
 #define LOG_EV(c) do { if (g_log && g_log_n < g_log_cap) g_log[g_log_n++] = (c); } while (0)
 #define ORC_COUNT_NODE(closest) do { g_cnt[(closest) ? 0 : 2]++; LOG_EV('n'); } while (0)
 #define ORC_COUNT_TRI(closest) do { g_cnt[(closest) ? 1 : 3]++; LOG_EV('l'); } while (0)
-#define ORC_RAY_BEGIN(closest) LOG_EV((closest) ? 'C' : 'S')
+struct orc_scene; static void lab_flat_ray_fwd(const struct orc_scene* s, float ox, float oy, float oz, float dx, float dy, float dz, uint32_t ray_mask, float tmax, int closest);
+#define ORC_RAY_BEGIN(closest) do { LOG_EV((closest) ? 'C' : 'S'); lab_flat_ray_fwd(s, org.x, org.y, org.z, dir.x, dir.y, dir.z, ray_mask, h->t, closest); } while (0)
 #include "../../oracle/pt_oracle.c"
 
 ORC_API void lab_log(unsigned char* buf, uint64_t cap) { g_log = buf; g_log_cap = cap; g_log_n = 0; }
@@ -287,3 +288,57 @@ ORC_API int lab_rotate(orc_scene* s, int passes) {
   s->max_depth = depth_of(s, 0);
   return total;
 }
+
+/* ---- flat leaf-list experiment (round 3): every ray is tested against the boxes of ALL leaf links (pair leaves = a node over two
+ * triangles count as one), then only the leaves whose box it enters are tested.  Records, per ray, how many leaf boxes it enters
+ * (closest: tmax = inf; shadow: tmax = 1) and how many of them an any-hit walk tests before the first hit. ---- */
+typedef struct { float lo[3], hi[3]; int32_t a, b; } flat_leaf_t;
+static flat_leaf_t g_flat[4096]; static int g_nflat; static const orc_scene* g_flat_scene;
+static uint32_t* g_flat_log; static uint64_t g_flat_n, g_flat_cap;
+static void flat_collect(const orc_scene* s) {
+  g_nflat = 0; g_flat_scene = s;
+  for (uint32_t i = 0; i < s->n_nodes; ++i) {
+    const bnode_t* nd = &s->nodes[i];
+    for (int c = 0; c < 2; ++c) {
+      int32_t l = nd->link[c];
+      flat_leaf_t f;
+      if (l < 0) { memcpy(f.lo, nd->lo[c], 12); memcpy(f.hi, nd->hi[c], 12); f.a = ~l; f.b = -1; g_flat[g_nflat++] = f; }
+      else if (s->nodes[l].link[0] < 0 && s->nodes[l].link[1] < 0) {
+        memcpy(f.lo, nd->lo[c], 12); memcpy(f.hi, nd->hi[c], 12); f.a = ~s->nodes[l].link[0]; f.b = ~s->nodes[l].link[1]; g_flat[g_nflat++] = f; }
+    }
+  }
+  /* singles that are children of a pair node were added twice: drop singles whose triangle is in a pair */
+  int m = 0;
+  for (int i = 0; i < g_nflat; ++i) {
+    int dup = 0;
+    if (g_flat[i].b < 0) for (int j = 0; j < g_nflat; ++j) if (g_flat[j].b >= 0 && (g_flat[j].a == g_flat[i].a || g_flat[j].b == g_flat[i].a)) dup = 1;
+    if (!dup) g_flat[m++] = g_flat[i];
+  }
+  g_nflat = m;
+}
+ORC_API int lab_flat_begin(const orc_scene* s, uint32_t* log, uint64_t cap) { flat_collect(s); g_flat_log = log; g_flat_cap = cap; g_flat_n = 0; return g_nflat; }
+ORC_API uint64_t lab_flat_size(void) { return g_flat_n; }
+static void lab_flat_ray(const orc_scene* s, v3 org, v3 dir, uint32_t ray_mask, float tmax, int closest) {
+  if (!g_flat_log || s != g_flat_scene || g_flat_n >= g_flat_cap) return;
+  v3 inv = V(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  int entered = 0, tested = 0, done = 0, entered2 = 0;
+  hit_t h; h.t = tmax; h.u = h.v = 0; h.id = UINT32_MAX; h.tri = 0;
+  /* pass 1: nearest box first */
+  float best_tn = INFINITY; int best = -1;
+  for (int i = 0; i < g_nflat; ++i) { float tn; if (box_test(g_flat[i].lo, g_flat[i].hi, org, inv, tmax, &tn)) { ++entered; if (tn < best_tn) { best_tn = tn; best = i; } } }
+  if (closest && best >= 0) {
+    tri_test(&s->tris_sorted[g_flat[best].a], org, dir, ray_mask, 0.0f, &h, 1);
+    if (g_flat[best].b >= 0) tri_test(&s->tris_sorted[g_flat[best].b], org, dir, ray_mask, 0.0f, &h, 1);
+    for (int i = 0; i < g_nflat; ++i) { float tn; if (i != best && box_test(g_flat[i].lo, g_flat[i].hi, org, inv, h.t, &tn)) ++entered2; }
+  }
+  if (!closest) {
+    for (int i = 0; i < g_nflat && !done; ++i) { float tn; if (box_test(g_flat[i].lo, g_flat[i].hi, org, inv, tmax, &tn)) {
+      ++tested;
+      if (tri_test(&s->tris_sorted[g_flat[i].a], org, dir, ray_mask, 0.0f, &h, 0)) done = 1;
+      else if (g_flat[i].b >= 0 && tri_test(&s->tris_sorted[g_flat[i].b], org, dir, ray_mask, 0.0f, &h, 0)) done = 1;
+    } }
+  }
+  g_flat_log[g_flat_n++] = (uint32_t)closest | ((uint32_t)entered << 4) | ((uint32_t)tested << 12) | ((uint32_t)entered2 << 20) | ((uint32_t)done << 28);
+}
+
+static void lab_flat_ray_fwd(const struct orc_scene* s, float ox, float oy, float oz, float dx, float dy, float dz, uint32_t ray_mask, float tmax, int closest) { lab_flat_ray(s, V(ox, oy, oz), V(dx, dy, dz), ray_mask, tmax, closest); }

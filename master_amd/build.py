@@ -3,6 +3,7 @@
 The library is the product: there is no CPU fallback and no JIT cache.  Flags:
   -ffp-contract=off   fusion happens only where the sources spell fmaf() (arithmetic contract)
   -munsafe-fp-atomics LDS FP64 accumulation compiles to ds_add_f64, not a CAS loop
+  -fno-slp-vectorize  no packed FP32 math (v_pk_fma_f32 issues at half rate on gfx950)
 """
 import os
 import shutil
@@ -73,7 +74,9 @@ def _build(verbose, extra_flags):
         obj = os.path.join(objdir, src.replace("/", "_") + ("." + tag if tag else "") + ".o")
         cmd = [hipcc()] + common + list(variant_flags)
         if src.endswith(".hip"):
-            cmd += ["--offload-arch=gfx950", "-munsafe-fp-atomics"]
+            # -fno-slp-vectorize: the SLP vectoriser packs pairs of dot products into v_pk_fma_f32 / v_pk_mul_f32, which issue at half the rate of
+            # the scalar form on gfx950 and need v_mov / v_pk_mov to line their operands up: C2 +15 % without it (profiles/r03/ab_flat.txt)
+            cmd += ["--offload-arch=gfx950", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
         else:
             cmd += ["-x", "c++"]
         cmd += list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]

@@ -25,4 +25,10 @@ hipError_t launch_intersect(const SceneView& sv, bool wide, uint32_t stack_entri
 hipError_t launch_occluded(const SceneView& sv, bool wide, uint32_t stack_entries, uint32_t n, const mi_surface_point* a, const mi_surface_point* b,
                            float* out, hipStream_t stream);
 
+// the parity hooks through the flat leaf list (scenes with a leaf table; MI_PT_INTERSECT_FLAT=1)
+hipError_t launch_intersect_flat(const SceneView& sv, const float* table, uint32_t K, uint32_t n, const mi_surface_point* origins, const float* dirs,
+                                 mi_surface_point* out_hits, float* out_t, uint32_t* out_prim, hipStream_t stream);
+hipError_t launch_occluded_flat(const SceneView& sv, const float* table, uint32_t K, uint32_t k_mesh, uint32_t n, const mi_surface_point* a, const mi_surface_point* b,
+                                float* out, hipStream_t stream);
+
 }  // namespace mi

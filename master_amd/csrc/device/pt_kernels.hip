@@ -534,6 +534,62 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
                     F3(b[i].gnormal[0], b[i].gnormal[1], b[i].gnormal[2]));
 }
 
+// The parity hooks through the flat leaf list (MI_PT_INTERSECT_FLAT=1, scenes that have a leaf table): the same staging and the same
+// traverse_flat the megakernel's FLAT variants run, so adversarial rays (axis-parallel, grazing, on box faces) reach it directly.
+__global__ __launch_bounds__(kBlock) void k_intersect_flat(SceneView sv, const float* __restrict__ table, uint32_t K, uint32_t n, const mi_surface_point* __restrict__ origins,
+                                                          const float* __restrict__ dirs, mi_surface_point* __restrict__ out_hits, float* __restrict__ out_t,
+                                                          uint32_t* __restrict__ out_prim) {
+  extern __shared__ float4 smem[];
+  stage_scene_flat(smem, sv, table, K, threadIdx.x);
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const f3 pos = F3(origins[i].position[0], origins[i].position[1], origins[i].position[2]);
+  const f3 gn = F3(origins[i].gnormal[0], origins[i].gnormal[1], origins[i].gnormal[2]);
+  const f3 dir = F3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+  const f3 org = nudge(pos, gn, dir);
+  Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+  traverse_flat<false>(smem, (cfloat*)table, (K + 3u) >> 2, 0xFFFFFFFFu, org, dir, h, nullptr);
+  finish_hit(h);
+  if (out_t) out_t[i] = h.t;
+  if (out_prim) out_prim[i] = h.id;
+  if (out_hits) {
+    mi_surface_point o;
+    if (h.id == 0xFFFFFFFFu) {
+      for (int k = 0; k < 3; ++k) { o.position[k] = 0; o.gnormal[k] = 0; }
+      for (int k = 0; k < 9; ++k) o.tangent[k] = 0;
+      o.material_id = 0xFFFFFFFFu;
+    } else {
+      const Surf s = query_surface<9>(smem, sv, org, dir, h);
+      o.position[0] = s.position.x; o.position[1] = s.position.y; o.position[2] = s.position.z;
+      o.gnormal[0] = s.gnormal.x; o.gnormal[1] = s.gnormal.y; o.gnormal[2] = s.gnormal.z;
+      o.tangent[0] = s.tangent.c0.x; o.tangent[1] = s.tangent.c0.y; o.tangent[2] = s.tangent.c0.z;
+      o.tangent[3] = s.tangent.c1.x; o.tangent[4] = s.tangent.c1.y; o.tangent[5] = s.tangent.c1.z;
+      o.tangent[6] = s.tangent.c2.x; o.tangent[7] = s.tangent.c2.y; o.tangent[8] = s.tangent.c2.z;
+      o.material_id = s.material_id;
+    }
+    out_hits[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_occluded_flat(SceneView sv, const float* __restrict__ table, uint32_t K, uint32_t k_mesh, uint32_t n,
+                                                         const mi_surface_point* __restrict__ a, const mi_surface_point* __restrict__ b, float* __restrict__ out) {
+  extern __shared__ float4 smem[];
+  stage_scene_flat(smem, sv, table, K, threadIdx.x);
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  // Scene::occluded (Scene.cpp:151-180), as occluded() in pt_device.h
+  const f3 opos = F3(a[i].position[0], a[i].position[1], a[i].position[2]), ogn = F3(a[i].gnormal[0], a[i].gnormal[1], a[i].gnormal[2]);
+  const f3 tpos = F3(b[i].position[0], b[i].position[1], b[i].position[2]), tgn = F3(b[i].gnormal[0], b[i].gnormal[1], b[i].gnormal[2]);
+  const f3 direction = tpos - opos;
+  const f3 ao = opos + (ogn * (dot(ogn, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+  const f3 at = tpos + (tgn * (dot(tgn, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+  Hit h; h.t = 1.0f; h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+  traverse_flat<true>(smem, (cfloat*)table, (k_mesh + 3u) >> 2, k_mesh >= 32u ? 0xFFFFFFFFu : (1u << k_mesh) - 1u, ao, at - ao, h, nullptr);
+  out[i] = h.id != 0xFFFFFFFFu ? 0.f : 1.f;
+}
+
 // ---- host-callable launchers (declared in launch.h) ----
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
   return (lds_scene ? (p.flat_k ? size_t(kFlatLeafF4 * p.flat_k + 18u * p.flat_k + (p.sv.blob_f4 - p.sv.off_mats)) * 16 : size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16)
@@ -635,6 +691,20 @@ hipError_t launch_occluded(const SceneView& sv, bool wide, uint32_t stack_entrie
                                out);
   else hipLaunchKernelGGL(k_occluded<1>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), size_t(stack_entries) * kBlock * 4, stream, sv, stack_entries, n, a, b,
                      out);
+  return hipGetLastError();
+}
+
+hipError_t launch_intersect_flat(const SceneView& sv, const float* table, uint32_t K, uint32_t n, const mi_surface_point* origins, const float* dirs,
+                                 mi_surface_point* out_hits, float* out_t, uint32_t* out_prim, hipStream_t stream) {
+  const size_t lds = size_t(kFlatLeafF4 * K + 18u * K + (sv.blob_f4 - sv.off_mats)) * 16;
+  hipLaunchKernelGGL(k_intersect_flat, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, stream, sv, table, K, n, origins, dirs, out_hits, out_t, out_prim);
+  return hipGetLastError();
+}
+
+hipError_t launch_occluded_flat(const SceneView& sv, const float* table, uint32_t K, uint32_t k_mesh, uint32_t n, const mi_surface_point* a, const mi_surface_point* b,
+                                float* out, hipStream_t stream) {
+  const size_t lds = size_t(kFlatLeafF4 * K + 18u * K + (sv.blob_f4 - sv.off_mats)) * 16;
+  hipLaunchKernelGGL(k_occluded_flat, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, stream, sv, table, K, k_mesh, n, a, b, out);
   return hipGetLastError();
 }
 

@@ -33,7 +33,7 @@ struct mi_pt_handle {
   float4* blob = nullptr;
   uint4* qnodes = nullptr;
   uint4* qnodes4 = nullptr;
-  float* flat_table = nullptr; uint32_t flat_k = 0, flat_k_mesh = 0;  // flat leaf list of small scenes (traverse_flat, pt_device.h): leaf boxes + links, mesh leaves first
+  float* flat_table = nullptr; uint32_t flat_k = 0, flat_k_mesh = 0; float flat_amax = 0.0f;  // flat_amax: largest |coordinate| the padding of the table's boxes covers  // flat leaf list of small scenes (traverse_flat, pt_device.h): leaf boxes + links, mesh leaves first
   int2* plain_links = nullptr;    // the builder's links of every node in Morton positions (mi_pt_bvh_download); the blob's nodes carry pair leaves
   bool float_nodes = false;        // HBM-resident kernels read the full-precision nodes: the 16-bit grid is too coarse for this scene
   bool wide_nodes = false;         // the PT megakernel walks the wide nodes (every HBM-resident scene the 16-bit grid is fine enough for; MI_PT_WIDE_NODES=0/1 overrides)
@@ -202,6 +202,19 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
     else p.dyn_traverse = (want && h->sv.n_nodes >= 1u && p.lds_tables) ? 1u : 0u;
     if (p.flat_k) p.dyn_traverse = 0u;
   }
+}
+
+// MI_PT_INTERSECT_FLAT=1: the parity hooks run the flat leaf list (scenes that have a leaf table).  Its boxes are padded for rays that start within the
+// scene's bounds (cameras included), which is where a path's rays start; a hook call with a point beyond them takes the tree walk.
+bool hooks_use_flat(const mi_pt_handle* h, const mi_surface_point* a, const mi_surface_point* b, uint32_t n) {
+  const char* e = std::getenv("MI_PT_INTERSECT_FLAT");
+  if (!(e && std::atoi(e) != 0) || !h->flat_k) return false;
+  for (uint32_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      if (!(std::fabs(a[i].position[k]) <= h->flat_amax)) return false;
+      if (b && !(std::fabs(b[i].position[k]) <= h->flat_amax)) return false;
+    }
+  return true;
 }
 
 }  // namespace
@@ -379,6 +392,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
         for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(double(h->info.scene_lo[a])), std::fabs(double(h->info.scene_hi[a]))));
         for (const mi_camera& cam : s.cameras) for (int a = 0; a < 3; ++a) amax = std::max(amax, std::fabs(double(cam.position[a])));
         const double pad = amax * 0x1p-20 + 1e-30;
+        h->flat_amax = float(amax);
         const size_t k_pad = (leaves.size() + 3) / 4 * 4;
         std::vector<float> table(k_pad * 8, 0.0f);
         for (size_t k = leaves.size(); k < k_pad; ++k) table[8 * k + 3] = table[8 * k + 4] = table[8 * k + 5] = -1e30f;  // nothing enters a padding entry
@@ -971,6 +985,8 @@ int mi_pt_intersect(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_h), size_t(n) * sizeof(mi_surface_point))); tmp.p[2] = d_h;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_t), size_t(n) * 4)); tmp.p[3] = d_t;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_p), size_t(n) * 4)); tmp.p[4] = d_p;
+  if (hooks_use_flat(h, origins, nullptr, n)) HIP_TRY(mi::launch_intersect_flat(h->sv, h->flat_table, h->flat_k, n, d_o, d_d, d_h, d_t, d_p, h->stream));
+  else
   HIP_TRY(mi::launch_intersect(h->sv, h->wide_nodes, h->stack_entries_hbm, n, d_o, d_d, d_h, d_t, d_p, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (out_hits) HIP_TRY(hipMemcpy(out_hits, d_h, size_t(n) * sizeof(mi_surface_point), hipMemcpyDeviceToHost));
@@ -988,6 +1004,8 @@ int mi_pt_occluded(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins,
   int rc = upload(&d_a, origins, size_t(n) * sizeof(mi_surface_point)); tmp.p[0] = d_a; if (rc) return rc;
   rc = upload(&d_b, targets, size_t(n) * sizeof(mi_surface_point)); tmp.p[1] = d_b; if (rc) return rc;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_o), size_t(n) * 4)); tmp.p[2] = d_o;
+  if (hooks_use_flat(h, origins, targets, n)) HIP_TRY(mi::launch_occluded_flat(h->sv, h->flat_table, h->flat_k, h->flat_k_mesh, n, d_a, d_b, d_o, h->stream));
+  else
   HIP_TRY(mi::launch_occluded(h->sv, h->wide_nodes, h->stack_entries_hbm, n, d_a, d_b, d_o, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_visibility, d_o, size_t(n) * 4, hipMemcpyDeviceToHost));

@@ -581,7 +581,13 @@ static inline int box_test(const float lo[3], const float hi[3], v3 org, v3 inv,
   float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
   float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
   *tnear_out = tn;
-  return tn <= tf * 1.0000004f;
+  /* conservative like the device's slab test (pt_device.h box_test): a relative widening plus an absolute slack for the rounding of
+   * (plane - org) * inv at large |org * inv| — a ray that runs along a box edge must not lose the box (r03: three edge-on shadow rays of
+   * CornellBoxPhong were lost with the bare 4e-7 widening; brute force and the device found their hits).  Which boxes are opened never
+   * changes a result: the hit is the (t, id) minimum over the triangles tested. */
+  float sx = fabsf(org.x * inv.x), sy = fabsf(org.y * inv.y), sz = fabsf(org.z * inv.z);
+  float slack = ((sx < INFINITY ? sx : 0.0f) + (sy < INFINITY ? sy : 0.0f) + (sz < INFINITY ? sz : 0.0f)) * 2.5e-7f;
+  return tn <= tf * 1.000002f + slack;
 }
 
 static void traverse(const orc_scene* s, v3 org, v3 dir, uint32_t ray_mask, hit_t* h, int closest) {

@@ -226,6 +226,106 @@ def test_dynamic_fetch_traversal_is_bit_identical_per_path(monkeypatch, name):
     assert pt.last_launch().dynamic_fetch == (0 if pt.get_kernel() == ma.KERNEL_MEGA_LDS else 1)
 
 
+# ---- flat leaf list (traverse_flat): the default for LDS-resident scenes of <= 24 leaf links (r03) ----
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxPhong", "TestCaseFurnace", "TestCase1", "TestCase14", "DoubleLight", "MirrorAndAreaLight", "LightOverBox",
+                                  "IndirectCubeNone", "soup7", "soup31"])
+@pytest.mark.parametrize("beta", [1.0, 1.5])
+def test_flat_leaf_list_is_bit_identical_per_path(monkeypatch, name, beta):
+    """A uniform loop over the boxes of all leaf links (scalar operands), then per-lane tests of the leaves entered — no tree walk.  What is tested cannot
+    change the (t, id) minimum or an occlusion: per-path radiance and ray counts equal the tree walk's and the oracle's bit for bit, images differ by the
+    order of a pixel's FP64 sum at most; the one-sample frame mode is identical.  Covers single and pair leaves, light-only leaves (cut from a shadow
+    ray's mask), Phong / mirror materials, several lights, a beta outside {1, 2} (general variant) and tables of 25..32 leaves (forced on)."""
+    s = sb.random_soup(int(name[4:]), seed=5) if name.startswith("soup") else load_scene(name)
+    pt = ma.PathTracing(s, max_path=9, beta=beta)
+    w, h, spp = 48, 40, 6
+    xy = np.stack(np.meshgrid(np.arange(w), np.arange(h)), -1).reshape(-1, 2).astype(np.uint32)
+    xy, si = np.tile(xy, (spp, 1)), np.repeat(np.arange(spp, dtype=np.uint64), w * h)
+    out = {}
+    for flat in ("0", "1"):
+        monkeypatch.setenv("MI_PT_FLAT", flat)
+        rad, cnt = pt.trace_paths(w, h, xy, si, seed=21)
+        img = pt.render_rgbn(w, h, spp=spp, seed=21)
+        li = pt.last_launch()
+        frame = pt.render_rgbn(w, h, spp=1, seed=21, sample_offset=3)
+        pt.set_instrumented(True)
+        ins = pt.render_rgbn(w, h, spp=spp, seed=21)
+        ist = pt.last_stats
+        pt.set_instrumented(False)
+        out[flat] = (rad, cnt, img, frame, (pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays), li.flat_leaves, ins, ist)
+    a, b = out["0"], out["1"]
+    assert a[5] == 0 and 1 <= b[5] <= 32
+    assert np.isclose(a[0], b[0], rtol=0, atol=0, equal_nan=True).all() and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2][..., 3], b[2][..., 3]) and np.allclose(a[2], b[2], rtol=1.2e-7, atol=0, equal_nan=True)
+    assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)) and a[4] == b[4]
+    # the instrumented variant renders the same image; it counts every box of the padded table per ray and two triangles per leaf entered
+    assert np.array_equal(b[6][..., 3], b[2][..., 3]) and np.allclose(b[6], b[2], rtol=1.2e-7, atol=0, equal_nan=True)
+    assert b[7].nodes_closest == b[7].num_basic_rays * ((b[5] + 3) // 4 * 4) and b[7].tris_closest % 2 == 0
+    orad, ocnt = oracle.Oracle(s, max_path=9, beta=beta).trace_paths(w, h, xy, si, seed=21)
+    assert np.isclose(b[0], orad, rtol=0, atol=0, equal_nan=True).all() and np.array_equal(b[1], ocnt)
+    monkeypatch.delenv("MI_PT_FLAT")
+    pt.render_rgbn(w, h, spp=2, seed=1)
+    assert (pt.last_launch().flat_leaves != 0) == (b[5] <= 24)
+
+
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxPhong", "TestCaseFurnace", "TestCase0", "DoubleLight", "TestCase14", "LightOverBox", "soup31"])
+def test_flat_leaf_list_hooks_on_adversarial_rays(monkeypatch, name):
+    """Scene::intersect / occluded through the flat leaf list (MI_PT_INTERSECT_FLAT=1: the staging and traverse_flat of the megakernel) against the
+    oracle's brute force and its tree: random rays, axis-parallel rays (1 / 0 replaced by a finite stand-in), rays inside the planes of the scene's
+    quads (zero-thickness boxes), rays that start on vertices, on box corners and on the bounds of the table's padding.  The padded centre / half-extent
+    boxes must not lose a hit: t, primitive and SurfacePoint bytes are identical (up to the grazing-ray ambiguity stated below)."""
+    s = sb.random_soup(int(name[4:]), seed=5) if name.startswith("soup") else load_scene(name)
+    monkeypatch.setenv("MI_PT_INTERSECT_FLAT", "1")
+    pt, orc = ma.PathTracing(s), oracle.Oracle(s)
+    pt.render_rgbn(8, 8, spp=1, seed=1)
+    assert pt.last_launch().flat_leaves > 0
+    rng = np.random.default_rng(9)
+    n = 60000
+    lo, hi = s.positions.min(0), s.positions.max(0)
+    o = np.zeros(n, ma.SURFACE_DTYPE)
+    o["position"] = rng.uniform(lo, hi, (n, 3)); g = rng.normal(size=(n, 3)); o["gnormal"] = g / np.linalg.norm(g, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True); d = d.astype(np.float32)
+    k = n // 6
+    d[:k, rng.integers(0, 3, k)] = 0.0                                   # one zero component
+    ax = rng.integers(0, 3, k); d[k:2 * k] = 0.0; d[np.arange(k, 2 * k), ax] = rng.choice([-1.0, 1.0], k)   # axis-parallel
+    tri = s.indices[rng.integers(0, len(s.indices), k)]                  # start on vertices, head for other vertices (box corners, quad planes)
+    o["position"][2 * k:3 * k] = s.positions[tri[:, 0]]
+    tgt = s.positions[s.indices[rng.integers(0, len(s.indices), k), rng.integers(0, 3, k)]]
+    dv = tgt - s.positions[tri[:, 0]]; nz = np.linalg.norm(dv, axis=1) > 0
+    d[2 * k:3 * k][nz] = (dv[nz] / np.linalg.norm(dv[nz], axis=1, keepdims=True)).astype(np.float32)
+    w = rng.uniform(0, 1, (k, 3)); w /= w.sum(1, keepdims=True)          # start inside triangles, leave within their planes
+    tri2 = s.indices[rng.integers(0, len(s.indices), k)]
+    p = (s.positions[tri2] * w[:, :, None]).sum(1)
+    o["position"][3 * k:4 * k] = p
+    e = s.positions[tri2[:, 1]] - s.positions[tri2[:, 0]]; en = np.linalg.norm(e, axis=1, keepdims=True); en[en == 0] = 1
+    d[3 * k:4 * k] = (e / en).astype(np.float32)
+    o["position"][4 * k:5 * k] = np.where(rng.integers(0, 2, (k, 3)) == 0, lo, hi)   # corners of the scene box
+
+    def tg_of(o):
+        tg = np.zeros(n, ma.SURFACE_DTYPE)
+        tg["position"] = np.roll(o["position"], 17, axis=0); tg["gnormal"] = np.roll(o["gnormal"], 5, axis=0)
+        return tg
+
+    # A ray that grazes a triangle (|den| -> 0) can be accepted by the FP32 Moeller-Trumbore test at a point a few 1e-6 OUTSIDE the triangle's box — no
+    # finite padding makes a box test agree with brute force there, and the walks (oracle tree, device tree with pair leaves, flat list) may then open
+    # different boxes.  So: the flat list equals the oracle's brute force or its tree on EVERY ray, both on all but a handful of these edge-on rays, and
+    # whenever tree and brute force agree it agrees with them (random path rays never get there: 0 mismatches in 17.7 M paths, profiles/r02/parity_sweep.txt).
+    gh, gt, gp = pt.intersect(o, d)
+    oh, ot, op = orc.intersect(o, d)
+    gv, ov = pt.occluded(o, tg_of(o)), orc.occluded(o, tg_of(o))
+    orc.set_use_bvh(False)                                               # brute force: no box test at all
+    bh, bt, bp = orc.intersect(o, d)
+    bv = orc.occluded(o, tg_of(o))
+    tree_ok = (gp == op) & (gt == ot); brute_ok = (gp == bp) & (gt == bt)
+    assert (tree_ok | brute_ok).all() and (tree_ok & brute_ok).sum() >= n - 12
+    assert all(gh[i].tobytes() == (oh[i] if tree_ok[i] else bh[i]).tobytes() for i in np.nonzero(~(tree_ok & brute_ok))[0])
+    both = tree_ok & brute_ok
+    assert gh[both].tobytes() == oh[both].tobytes()
+    assert ((gv == ov) | (gv == bv)).all() and ((gv == ov) & (gv == bv)).sum() >= n - 12
+    monkeypatch.setenv("MI_PT_INTERSECT_FLAT", "0")                      # the device's tree walk obeys the same statement
+    th, tt, tp = pt.intersect(o, d)
+    assert (((tp == op) & (tt == ot)) | ((tp == bp) & (tt == bt))).all() and ((tp == gp) & (tt == gt)).sum() >= n - 12
+
+
 def test_bench_two_ranks_share_the_gpu_on_the_c5_shape(tmp_path):
     """the N > 1 path of bench.py rehearsed on this box — two ranks (gloo, both on the one GPU), the C5 stand-in at 3840x2160 with the
     pixel-tile shard: launcher contract (torch.distributed.run, 127.0.0.1), barrier + max-over-ranks timing, one JSON line on rank 0 that carries the

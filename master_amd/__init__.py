@@ -465,7 +465,8 @@ class PathTracing:
         return list(t)
 
     def wait(self, ticket, copy=True):
-        """mi_pt_wait: the frame's [H][W][4] sums (a view of the handle's pinned buffer unless copy) and its statistics."""
+        """mi_pt_wait: the frame's [H][W][4] sums and its statistics.  copy=False returns a VIEW of the handle's pinned buffer: it is only valid until
+        the batch slot is enqueued again (BATCHES_IN_FLIGHT launches later) and is overwritten then without notice — copy it or consume it at once."""
         p, st = C.POINTER(C.c_float)(), PtStats()
         _check(lib().mi_pt_wait(self._h, ticket, C.byref(p), C.byref(st)))
         self.last_stats = st
@@ -498,16 +499,36 @@ class PathTracing:
                 k0 = j * batch
                 tickets[j] = self.render_frames_async(w, h, min(batch, n_frames - k0), seed, first + k0, camera_id, window)
 
-        for j in range(BATCHES_IN_FLIGHT - 1):
-            enqueue(j)
-        for k in range(n_frames):
-            j, f = divmod(k, batch)
-            if f == 0:
-                enqueue(j + BATCHES_IN_FLIGHT - 1)
-            self.wait_add(tickets[j][f], view)  # _commit_images (Technique.cpp:222-226)
-            st.num_samples += 1
-            st.num_basic_rays += self.last_stats.num_basic_rays
-            st.num_shadow_rays += self.last_stats.num_shadow_rays
+        import time
+        t_last = time.perf_counter()
+        done = {}  # tickets already waited for, per batch
+        try:
+            for j in range(BATCHES_IN_FLIGHT - 1):
+                enqueue(j)
+            for k in range(n_frames):
+                j, f = divmod(k, batch)
+                if f == 0:
+                    enqueue(j + BATCHES_IN_FLIGHT - 1)
+                self.wait_add(tickets[j][f], view)  # _commit_images (Technique.cpp:222-226)
+                done[j] = f + 1
+                now = time.perf_counter()
+                st.num_samples += 1
+                st.num_basic_rays += self.last_stats.num_basic_rays
+                st.num_shadow_rays += self.last_stats.num_shadow_rays
+                st.total_time += now - t_last
+                # one record per frame, like render() (Technique.cpp:61-76); rms / abs errors need a reference image and stay 0 here
+                st.records.append(dict(sample_index=st.num_samples - 1, rms_error=0.0, abs_error=0.0, clock_time=st.total_time, frame_duration=now - t_last,
+                                       numeric_errors=int(self.last_stats.numeric_errors)))
+                t_last = now
+        finally:
+            # drain: a wait or an enqueue that raised must not leave batches pending on the handle (every later render_frames_async would then
+            # fail with 'batches are pending' because the tickets are lost) — the C++ adapter's _drain()
+            for j, ts in tickets.items():
+                for t in ts[done.get(j, 0):]:
+                    try:
+                        self.wait(t, copy=False)
+                    except MiError:
+                        pass
 
     def render(self, view, seed=0, camera_id=0, reference=None, window=None, spp=1):
         """Technique::render (Technique.cpp:15-77): adds `spp` frames (default 1, as the reference) to

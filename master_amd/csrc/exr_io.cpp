@@ -185,11 +185,15 @@ int mi_exr_load_rgbn(const char* path, uint32_t* width, uint32_t* height, float*
   if (line_size == 0 || (compression == 0 && size_t(h) > d.size() / line_size) || size_t(n_chunks) > d.size() / 8)
     return mi::fail(MI_ERR_IO, bad + "truncated pixel data.");  // also bounds the allocation by the file size (a compressed line needs >= 8 bytes of chunk header)
   if (size_t(w) * size_t(h) > (size_t(1) << 31)) return mi::fail(MI_ERR_UNSUPPORTED, bad + "image too large.");
+  // compressed files: zlib / RLE expand by at most ~1032 : 1 / 128 : 1, so the pixel data cannot be larger than that multiple of the file — a
+  // crafted 32 KB header must not reach a 32 GiB calloc before its first chunk is looked at
+  if (compression != 0 && size_t(h) * line_size / 1100 > d.size()) return mi::fail(MI_ERR_IO, bad + "truncated pixel data.");
   float* out = static_cast<float*>(std::calloc(size_t(w) * size_t(h) * 4, sizeof(float)));
   if (!out) return mi::fail(MI_ERR_OUT_OF_MEMORY, "out of memory");
   bool has_denom = false;
   for (const Chan& c : chans) has_denom |= c.name == "denom";
   std::vector<uint8_t> raw;
+  std::vector<uint8_t> seen(size_t(n_chunks), 0);
   for (int64_t k = 0; k < n_chunks; ++k) {
     uint64_t off;
     if (o + size_t(k) * 8 + 8 > d.size()) { std::free(out); return mi::fail(MI_ERR_IO, bad + "truncated offset table."); }
@@ -198,6 +202,9 @@ int mi_exr_load_rgbn(const char* path, uint32_t* width, uint32_t* height, float*
     int32_t yy, stored; std::memcpy(&yy, &d[off], 4); std::memcpy(&stored, &d[off + 4], 4);
     const int64_t first = int64_t(yy) - win[1];
     if (first < 0 || first >= h || stored < 0 || size_t(stored) > d.size() - off - 8) { std::free(out); return mi::fail(MI_ERR_IO, bad + "bad scan line."); }
+    // every chunk starts on a chunk boundary and is seen exactly once: rows a malformed table left uncovered would stay 0 silently
+    if (first % lines_per_chunk != 0 || seen[size_t(first / lines_per_chunk)]) { std::free(out); return mi::fail(MI_ERR_IO, bad + "misplaced or repeated scan-line chunk."); }
+    seen[size_t(first / lines_per_chunk)] = 1;
     const int64_t lines = h - first < lines_per_chunk ? h - first : lines_per_chunk;
     if (!decode_chunk(compression, &d[off + 8], size_t(stored), size_t(lines) * line_size, raw)) { std::free(out); return mi::fail(MI_ERR_IO, bad + "corrupt scan-line chunk."); }
     size_t p = 0;

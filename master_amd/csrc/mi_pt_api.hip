@@ -1069,19 +1069,20 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
     unsigned long long over = 0;
     HIP_TRY(hipMemcpy(&over, h->d_counters + 15, sizeof over, hipMemcpyDeviceToHost));
     if (over) { *overflow = true; HIP_TRY(hipMemsetAsync(h->d_counters + 15, 0, sizeof over, stream)); return MI_OK; }
-    // values [items][16 B] | shadow rays [items][32 B] | occlusion bytes [items] | ray count + chunk cursor (visibility stage)
-    const size_t n_it = total ? total : 1, occl_bytes = (n_it + 255) / 256 * 256;
-    int rc = ensure(reinterpret_cast<void**>(&h->bpt_values), &h->bpt_values_bytes, n_it * 48 + occl_bytes + 256);
-    if (rc) return rc;
-    ws.values = h->bpt_values;
-    ws.rays = h->bpt_values + n_it;
-    ws.occl = reinterpret_cast<uint8_t*>(h->bpt_values + 3 * n_it);
-    ws.pool = reinterpret_cast<uint32_t*>(ws.occl + occl_bytes);
     // The visibility stage pays where a launch holds many more shadow rays than the chip has lanes (524 288 resident) and a node is a dependent
     // fetch from L2 / HBM: LivingRoomLit (20 M items per launch) +13 %, CornellBoxSpecular (5 M) +8 %; MetalRings (0.6 M) -4 %, scenes walked
     // in LDS -8 % (profiles/r02/ab_bpt_visibility.txt).  MI_BPT_DYN_VIS=0/1 forces it off / on.
     ws.dyn_vis = (!lds && total >= (2u << 20)) ? 1u : 0u;
     if (const char* e = std::getenv("MI_BPT_DYN_VIS")) ws.dyn_vis = std::atoi(e) != 0 ? 1u : 0u;
+    // values [items][16 B]; with the visibility stage also: shadow rays [items][32 B] | occlusion bytes [items] | ray count + chunk cursor
+    // (launches without it — LDS-resident scenes, fewer than 2 M items — hold the values alone: a third of the bytes)
+    const size_t n_it = total ? total : 1, occl_bytes = ws.dyn_vis ? (n_it + 255) / 256 * 256 : 0;
+    int rc = ensure(reinterpret_cast<void**>(&h->bpt_values), &h->bpt_values_bytes, n_it * (ws.dyn_vis ? 48 : 16) + occl_bytes + 256);
+    if (rc) return rc;
+    ws.values = h->bpt_values;
+    ws.rays = ws.dyn_vis ? h->bpt_values + n_it : nullptr;
+    ws.occl = ws.dyn_vis ? reinterpret_cast<uint8_t*>(h->bpt_values + 3 * n_it) : nullptr;
+    ws.pool = ws.dyn_vis ? reinterpret_cast<uint32_t*>(ws.occl + occl_bytes) : nullptr;
     ws.vis_th = 16u; ws.vis_wide = p.wide_nodes == 1u ? 1u : 0u;
     if (const char* e = std::getenv("MI_BPT_VIS_TH")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ws.vis_th = uint32_t(v); }
     if (const char* e = std::getenv("MI_BPT_VIS_WIDE")) ws.vis_wide = std::atoi(e) != 0 ? 1u : 0u;

@@ -74,7 +74,8 @@ std::string SceneData::validate() const {
     // parameters a kernel would turn into NaNs or a black surface without saying so (an adapter that forgot to copy them)
     for (int k = 0; k < 3; ++k)
       if (!std::isfinite(m.diffuse[k]) || !std::isfinite(m.specular[k])) return "non-finite material colour";
-    if (m.type == MI_BSDF_PHONG && !(m.power > 0.0f && std::isfinite(m.power))) return "Phong material needs a positive, finite exponent (PhongBSDF, BSDF.cpp:306-315)";
+    // the reference accepts an exponent of 0 (loader.cpp:220-224 defaults AI_MATKEY_SHININESS to 0; PhongBSDF, BSDF.cpp:306-315: 2 pi specular / 1)
+    if (m.type == MI_BSDF_PHONG && !(m.power >= 0.0f && std::isfinite(m.power))) return "Phong material needs a non-negative, finite exponent (PhongBSDF, BSDF.cpp:306-315)";
     if (m.type == MI_BSDF_TRANSMISSION && !(std::isfinite(m.ior_internal) && std::isfinite(m.ior_external) && m.ior_internal != 0.0f && m.ior_external != 0.0f))
       return "transmission material needs finite, non-zero indices of refraction (TransmissionBSDF, BSDF.cpp:467-470)";
   }
@@ -244,6 +245,10 @@ class RowPool {
   // fn(row) for every row in [0, rows), chunks of rows handed out by an atomic counter; the caller works too
   template <class F> void run(uint32_t rows, F fn) {
     if (workers_.empty() || rows < 64) { for (uint32_t r = 0; r < rows; ++r) fn(r); return; }
+    // one job at a time: job_ / rows_ / next_ / busy_ describe THE job.  A second caller (another thread adding another handle's frame — ctypes
+    // releases the GIL, the adapter may run one thread per GPU) does its rows itself instead of waiting for the pool.
+    std::unique_lock<std::mutex> owner(run_m_, std::try_to_lock);
+    if (!owner.owns_lock()) { for (uint32_t r = 0; r < rows; ++r) fn(r); return; }
     const std::function<void(uint32_t)> f = fn;
     {
       std::lock_guard<std::mutex> g(m_);
@@ -281,7 +286,7 @@ class RowPool {
     }
   }
   std::vector<std::thread> workers_;
-  std::mutex m_;
+  std::mutex m_, run_m_;  // run_m_: held by the caller whose job the pool is running
   std::condition_variable cv_, done_;
   const std::function<void(uint32_t)>* job_ = nullptr;
   uint32_t rows_ = 0;

@@ -81,7 +81,8 @@ def test_scene_validation_rejects_bad_descriptions(cornell):
     with pytest.raises(ma.MiError):  # empty scene
         ma.Scene.from_arrays(np.zeros((0, 3)), np.zeros((0, 9)), np.zeros((0, 3)), [0], [], s.materials, s.lights, s.cameras)
     # material parameters an adapter forgot to copy: an error, not a black or NaN image
-    for kind, field, value, word in ((ma.BSDF_PHONG, "power", 0.0, "exponent"), (ma.BSDF_TRANSMISSION, "ior_internal", 0.0, "refraction"), (ma.BSDF_DIFFUSE, "power", 0.0, None)):
+    for kind, field, value, word in ((ma.BSDF_PHONG, "power", -1.0, "exponent"), (ma.BSDF_PHONG, "power", float("nan"), "exponent"), (ma.BSDF_PHONG, "power", 0.0, None),  # exponent 0 is the reference's default (loader.cpp:220-224)
+                                    (ma.BSDF_TRANSMISSION, "ior_internal", 0.0, "refraction"), (ma.BSDF_DIFFUSE, "power", 0.0, None)):
         mats = [ma.Material.from_buffer_copy(m) for m in s.materials]
         surf = next(i for i, m in enumerate(mats) if m.type == ma.BSDF_DIFFUSE)
         mats[surf].type = kind; mats[surf].ior_external = 1.0; mats[surf].ior_internal = 1.5; mats[surf].power = 10.0
@@ -178,3 +179,36 @@ def test_view_add_frame_is_commit_images():
         assert np.array_equal(view, ref)
     with pytest.raises(ma.MiError):
         ma.view_add_frame(np.zeros((4, 4, 4)), np.zeros((4, 4, 4), np.float32), (2, 2, 3, 3))
+
+def test_view_add_frame_from_several_threads_at_once():
+    """the host pool behind mi_view_add_frame / mi_pt_wait_add is process-wide and ctypes releases the GIL — two threads adding
+    frames to their own views at the same time (one thread per handle or GPU) must neither corrupt a sum nor hang: the pool runs one job, a second
+    caller adds its rows itself."""
+    import threading
+    h, w, rounds, n_threads = 256, 192, 40, 4
+    rng = np.random.default_rng(3)
+    frames = [rng.random((h, w, 4), dtype=np.float32) for _ in range(n_threads)]
+    views = [np.zeros((h, w, 4), np.float64) for _ in range(n_threads)]
+    start = threading.Barrier(n_threads)
+    errors = []
+
+    def work(i):
+        try:
+            start.wait()
+            for _ in range(rounds):
+                ma.view_add_frame(views[i], frames[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errors and not any(t.is_alive() for t in ts)
+    for i in range(n_threads):
+        want = np.zeros((h, w, 4), np.float64)
+        for _ in range(rounds):
+            want += frames[i].astype(np.float64)
+        assert np.array_equal(views[i], want)
+

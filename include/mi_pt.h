@@ -269,6 +269,9 @@ int mi_pt_device_count(void);
 const char* mi_pt_last_error(void);
 
 int mi_pt_abi_version(void);
+/* Hash of the sources, headers and compiler flags this library was built from (master_amd/build.py: source_hash).  __graft_entry__.build()
+ * rebuilds unless it equals the hash of the tree next to the library — a stale prebuilt library is never reused silently. */
+const char* mi_pt_build_id(void);
 
 /* Kernel variant selection (for measurement; default MI_PT_KERNEL_AUTO). */
 enum {

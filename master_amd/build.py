@@ -40,18 +40,50 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s if isinstance(s, str) else s[0]) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+BUILD_ID_TAG = b"MI_PT_BUILD_ID="
+
+
+def source_hash(extra_flags=()):
+    """sha256 over every source, header and flag that goes into the library: what `mi_pt_build_id()` of a library built from this tree returns."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted({os.path.normpath(os.path.join(CSRC, s if isinstance(s, str) else s[0])) for s in SOURCES + HEADERS} | {os.path.abspath(__file__)})
+    for f in files:
+        h.update(os.path.relpath(f, HERE).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(repr([e if isinstance(e, str) else list(e[:2]) + [e[2]] for e in SOURCES]).encode())
+    h.update(repr(list(extra_flags)).encode())
+    return h.hexdigest()[:32]
+
+
+def library_build_id(path=None):
+    """The id embedded in a built library (read from the bytes of the file, the library is not loaded), or None."""
+    path = path or LIB
+    try:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return None
+    i = blob.find(BUILD_ID_TAG)
+    if i < 0:
+        return None
+    j = i + len(BUILD_ID_TAG)
+    return blob[j:j + 32].decode("ascii", "replace")
+
+
+def needs_build(extra_flags=()):
+    """True unless the library on disk was built from exactly these sources and flags.  Timestamps are not trusted: a prebuilt *.so travels to the
+    GPU box next to sources that may have changed since (VERDICT r02 #12)."""
+    return library_build_id() != source_hash(extra_flags)
 
 
 def build(force=False, verbose=False, extra_flags=(), out=None):
     """out: alternative output path (A/B variants, e.g. build(extra_flags=["-DX"], out="libmi_pt_x.so"))."""
     global LIB
-    if out is None and not force and not needs_build():
+    if out is None and not force and not needs_build(extra_flags):
         return LIB
     lib_saved = LIB
     if out is not None:
@@ -79,6 +111,8 @@ def _build(verbose, extra_flags):
             cmd += ["--offload-arch=gfx950", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
         else:
             cmd += ["-x", "c++"]
+        if src == "scene_host.cpp":  # mi_pt_build_id(): the hash of what this library is built from
+            cmd += ['-DMI_PT_BUILD_ID_STRING="%s%s"' % (BUILD_ID_TAG.decode(), source_hash(extra_flags))]
         cmd += list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

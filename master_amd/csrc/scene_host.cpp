@@ -312,6 +312,11 @@ extern "C" {
 
 const char* mi_pt_last_error(void) { return mi::g_last_error.c_str(); }
 int mi_pt_abi_version(void) { return MI_PT_ABI_VERSION; }
+#ifndef MI_PT_BUILD_ID_STRING
+#define MI_PT_BUILD_ID_STRING "MI_PT_BUILD_ID=unknown"
+#endif
+// "MI_PT_BUILD_ID=<hash>": the tag is in the binary so that master_amd/build.py can read the id without loading the library
+const char* mi_pt_build_id(void) { static const char id[] = MI_PT_BUILD_ID_STRING; return id + 15; }
 
 static int finish_scene(mi_scene* s, mi_scene** out) {
   std::string err = s->data.validate();

@@ -33,6 +33,20 @@ def test_library_exports_every_declared_symbol():
     assert L.mi_pt_abi_version() == 2  # 2: + mi_pt_render_async / mi_pt_wait / mi_pt_last_launch
 
 
+def test_library_is_built_from_this_tree():
+    """a prebuilt libmi_pt.so travels to the GPU box next to the sources; build() must not reuse one it cannot prove matches them.  The
+    library carries the hash of its sources, headers and flags (mi_pt_build_id), readable without loading it; needs_build() compares hashes, not timestamps."""
+    import ctypes
+    from master_amd import build as mb
+    L = ma.lib()
+    L.mi_pt_build_id.restype = ctypes.c_char_p
+    bid = L.mi_pt_build_id().decode()
+    assert len(bid) == 32 and bid == mb.library_build_id(ma.LIB_PATH)
+    if os.path.samefile(ma.LIB_PATH, mb.LIB):
+        assert bid == mb.source_hash() and not mb.needs_build()
+        assert mb.source_hash(["-DX"]) != bid  # other flags = another library
+
+
 def test_no_torch_or_cxx_types_cross_the_boundary():
     src = open(os.path.join(ROOT, "include", "mi_pt.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)  # comments may name the reference's C++ types

@@ -19,9 +19,10 @@ Prints ONE JSON line on rank 0.  Its `roofline` block never shows a fraction of 
   * For a scene that is read from HBM/L2, `achieved` is SURVEY 8(d)'s algorithmic bytes per segment (visit counters of the
     instrumented kernel on the same workload) x the segments of one launch / the launch time.
 
-At N = 1 the line also carries — with --time-to-rmse — `time_to_rmse` (the second half of BASELINE.json's metric, outside the timed region) and `hbm_workload`: one HBM-resident configuration (BASELINE configs[3] through its stand-in,
-the 269 k-triangle atrium at 1920x1080, 256 spp, unbounded paths) timed after the primary region with its own
-ms_per_step, algorithmic bytes and measured traffic.
+At N = 1 the line also carries `time_to_rmse` (the second half of BASELINE.json's metric, outside the timed region; --no-time-to-rmse skips it),
+`hbm_workload`: one HBM-resident configuration (BASELINE configs[3] through its stand-in, the 269 k-triangle atrium at 1920x1080, 256 spp,
+unbounded paths) timed after the primary region with its own ms_per_step, algorithmic bytes and measured traffic, and `hbm_workload_beyond_cache`:
+the 2 M-triangle atrium (480 MB of scene: beyond the 256 MB Infinity Cache), the launch that really reaches HBM.
 """
 import argparse
 import json
@@ -82,12 +83,42 @@ def cpu_model():
     return "unknown"
 
 
+def native_oracle_build():
+    """The CPU-baseline leg runs the restatement compiled for THIS host: -O2 -march=native, default FP contraction — a throughput
+    build next to the bit-exact checker build (oracle/Makefile: -mfma -ffp-contract=off), made here because -march=native must match the box."""
+    import subprocess
+    import tempfile
+
+    out = os.path.join(tempfile.mkdtemp(prefix="mi_oracle_native_"), "libpt_oracle_native.so")
+    cmd = ["gcc", "-O2", "-march=native", "-std=gnu11", "-fPIC", "-fvisibility=hidden", "-pthread", "-shared", "-o", out,
+           os.path.join(ROOT, "oracle", "pt_oracle.c"), "-lm", "-pthread"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out, " ".join(cmd[1:4])
+
+
+def embree_on_host():
+    import subprocess
+
+    try:
+        return "embree" in subprocess.run(["ldconfig", "-p"], capture_output=True, text=True, timeout=10).stdout.lower()
+    except Exception:  # noqa: BLE001
+        return False
+
+
 def cpu_baseline(scene, args, budget_s=12.0):
     """CPU restatement (oracle, kind "port") timed on this host's cores on a bounded sample of the
     same workload: same scene / resolution / max path, fewer samples per pixel."""
     import oracle
 
     threads = effective_cpus()
+    flags = "oracle/Makefile build (-O2 -mfma -ffp-contract=off: the bit-exact checker)"
+    try:
+        lib, flags = native_oracle_build()
+        oracle.ORACLE_LIB = lib
+        oracle.build = lambda: lib
+        oracle._lib = None
+    except Exception as e:  # noqa: BLE001  (no compiler on the box: fall back to the checker build and say so)
+        flags += "; native build failed: %r" % (e,)
     orc = oracle.Oracle(scene, lights=1.0, roulette=0.9, beta=1.0, max_path=args.max_path)
     orc.render_rgbn(args.width, args.height, spp=1, seed=1, threads=threads)  # warm-up, page-in
     spp_done, segs, t0 = 0, 0, time.perf_counter()
@@ -98,7 +129,8 @@ def cpu_baseline(scene, args, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or spp_done >= args.spp:
             break
-    return {"value": segs / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+    return {"value": segs / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(), "build": flags,
+            "embree_on_host": embree_on_host(),
             "sample": "%s %dx%d max_path %s, %d spp of %d, %.1f s, CPU restatement of reference PT (own BVH, non-Embree), pthreads over 32x32 tiles" % (
                 args.scene, args.width, args.height, args.max_path, spp_done, args.spp, dt)}
 
@@ -129,6 +161,8 @@ def roofline_block(ma, pt, ist, seg_per_launch, avg_ms, li, key):
     kernel = pt.get_kernel()
     lds_scene = kernel == ma.KERNEL_MEGA_LDS
     node_bytes = 64.0  # SURVEY 8(d) prices a visited node at 64 B whatever the build stores (32-byte quantised nodes read half of that)
+    if li.flat_leaves:
+        node_bytes = 32.0  # flat leaf list: N counts the leaf-table entries a ray is tested against (32 B each, scalar loads), T two triangles per leaf entered
     b_sample, terms = algorithmic_bytes_per_sample(ist, wavefront=kernel == ma.KERNEL_WAVEFRONT, node_bytes=node_bytes)
     launch_s = avg_ms * 1e-3
     pmc = traffic_entry(key)
@@ -157,6 +191,10 @@ def roofline_block(ma, pt, ist, seg_per_launch, avg_ms, li, key):
         rl["note"] = "bytes served by L2 / Infinity Cache count towards `achieved`; `traffic` is what the PMC counters saw leave the L2"
     rl["frac"] = rl["achieved"] / HBM_PEAK_GBS
     assert rl["frac"] <= 1.0, "roofline.frac must be a fraction"
+    if traffic is not None:  # what the PMC counters saw leave the L2, against the HBM peak (VERDICT r02 #4c): the algorithmic figure counts cache-served bytes too
+        rl["hbm_measured_frac"] = traffic / launch_s / 1e9 / HBM_PEAK_GBS
+    if li.flat_leaves:
+        rl["traversal"] = "flat leaf list: %d leaf boxes per ray in one wave-uniform loop (scalar operands), then per-lane tests of the leaves entered" % li.flat_leaves
     # VALU view: issue utilisation and active lanes per issued instruction need PMC counters (separate rocprofv3 passes); the
     # traversal loops' lane efficiency is measured in this run by the instrumented kernel
     valu = {"traversal_lane_efficiency_in_run": {"closest": terms["simd_efficiency_closest_traversal"], "shadow": terms["simd_efficiency_shadow_traversal"]},
@@ -191,6 +229,8 @@ def main():
     ap.add_argument("--time-to-rmse", action="store_true", help="(default since round 3; kept so older command lines still parse)")
     ap.add_argument("--hbm-scene", default="atrium")
     ap.add_argument("--hbm-size", default="1920x1080x256", help="WxHxSPP of the HBM-resident workload (BASELINE configs[3] shape)")
+    ap.add_argument("--hbm-scene2", default="atrium:2000000", help="second HBM workload: a scene larger than the Infinity Cache ('' skips it)")
+    ap.add_argument("--hbm-size2", default="1920x1080x64")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses N ranks on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="map every rank onto the visible GPUs modulo their count (rehearsal only)")
     args = ap.parse_args()
@@ -345,7 +385,9 @@ def main():
             out["per_rank"] = per_rank
     del pt
     if rank == 0 and world == 1 and not args.no_hbm_workload:
-        out["hbm_workload"] = hbm_workload(ma, torch, args, seed)
+        out["hbm_workload"] = hbm_workload(ma, torch, args, seed, args.hbm_scene, args.hbm_size)
+        if args.hbm_scene2:  # a scene beyond the 256 MB Infinity Cache: the kernel that really reaches HBM
+            out["hbm_workload_beyond_cache"] = hbm_workload(ma, torch, args, seed, args.hbm_scene2, args.hbm_size2)
     if rank == 0 and world == 1 and not args.no_time_to_rmse and args.scene == "CornellBoxDiffuse":
         try:  # the second half of BASELINE.json's metric; never allowed to cost the line
             out["time_to_rmse"] = time_to_rmse(ma, scene, args)
@@ -390,11 +432,11 @@ def time_to_rmse(ma, scene, args, target=0.01, frame_spp=16, ref_spp=65536, max_
             "includes": "per-call framebuffer download and host-side RMS (ImageView.cpp:60-85)"}
 
 
-def hbm_workload(ma, torch, args, seed):
+def hbm_workload(ma, torch, args, seed, scene_name, size):
     """One HBM-resident configuration after the primary timed region: 1 warm-up + 2 steps, own ms_per_step and roofline."""
-    W, H, spp = [int(x) for x in args.hbm_size.split("x")]
+    W, H, spp = [int(x) for x in size.split("x")]
     t0 = time.perf_counter()
-    scene = load_scene(args.hbm_scene)
+    scene = load_scene(scene_name)
     t_scene = time.perf_counter() - t0
     pt = ma.PathTracing(scene, lights=1.0, roulette=0.9, beta=1.0, max_path=ma.PTRDIFF_MAX, device=torch.cuda.current_device())
     fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -418,9 +460,9 @@ def hbm_workload(ma, torch, args, seed):
     pt.set_instrumented(False)
     info = pt.bvh_info()
     avg_ms = sum(kernel_ms) / len(kernel_ms)
-    rl = roofline_block(ma, pt, ist, float(st.num_basic_rays), avg_ms, li, workload_key(args.hbm_scene, W, H, spp, 999))
+    rl = roofline_block(ma, pt, ist, float(st.num_basic_rays), avg_ms, li, workload_key(scene_name, W, H, spp, 999))
     return {"workload": "%s (procedural stand-in for BASELINE configs[3] CrytekSponza: %d triangles, BVH depth %d), PT, %dx%d, %d spp, unbounded paths, beta 1, roulette 0.9" % (
-                args.hbm_scene, info.n_triangles, info.max_depth, W, H, spp),
+                scene_name, info.n_triangles, info.max_depth, W, H, spp),
             "value": segs / elapsed / 1e6, "unit": "Msamples/s", "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3,
             "Mpaths_per_s": paths / elapsed / 1e6, "Mrays_per_s": (segs + shadow) / elapsed / 1e6,
             "scene_bytes_in_hbm": li.scene_bytes, "node_records": {0: "32-byte quantised binary", 1: "64-byte quantised wide (4 grandchildren)", 2: "64-byte float binary"}[li.wide_nodes],

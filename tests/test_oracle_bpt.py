@@ -25,6 +25,25 @@ def test_normalised_models_average_one(name, beta):
     assert abs(_mean(img) - 1.0) < 0.03, _mean(img)
 
 
+@pytest.mark.parametrize("parent,copies", [("TestCase31", ["TestCase35"]), ("TestCase33", ["TestCase37", "TestCase38", "TestCase39", "TestCase41"]),
+                                            ("TestCase30", ["TestCase32"])])
+def test_models_that_miss_the_constant_are_untuned_copies_of_normalised_ones(parent, copies):
+    """VERDICT r02 #3.  The author tuned each model's lamp energy until its image average reached unit_test.py's constant (energies like 53.9002,
+    775.314 ...).  TestCase35 / 37 / 38 / 39 / 41 (and 32) average 0.29 ... 1.33 through this build — but each carries, BIT FOR BIT, the energy of an
+    earlier model that does average 1.00 (31 -> 34, 35; 33 -> 36 ... 43; 30 -> 32; tools/testcase_energies.py over the reference's .blend files,
+    profiles/r03/testcase_lamp_energies.txt): copies with edited geometry or camera that were saved without re-normalising.  Nothing in the reader
+    (loader.cpp:293-456) or the sun-light terms (BSDF.cpp:164-193, BPT.cpp:192-225) is left to explain — the parent, read and rendered by the same
+    code, is on the constant."""
+    p = load_scene(parent)
+    img = oracle.Oracle(p, beta=2.0).bpt_render_rgbn(64, 64, spp=32, seed=3, threads=8)
+    assert abs(_mean(img) - 1.0) < 0.04, _mean(img)
+    for c in copies:
+        q = load_scene(c)
+        assert len(q.lights) == len(p.lights) == 1
+        assert np.array_equal(np.array(list(q.lights[0].exitance), np.float32).view(np.uint32), np.array(list(p.lights[0].exitance), np.float32).view(np.uint32))
+        assert list(q.lights[0].size) == list(p.lights[0].size) and q.lights[0].diffuse == p.lights[0].diffuse
+
+
 @pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxSpecular", "MirrorAndAreaLight"])
 def test_bpt_and_pt_agree(name):
     s = load_scene(name)

@@ -140,3 +140,26 @@ def test_flatten_covers_every_bsdf_class_of_the_reference():
         if c == "DeltaBSDF":  # abstract base of the two delta materials
             continue
         assert "dynamic_cast<const %s*>" % c in src, c
+
+
+def test_reference_patch_applies_cleanly():
+    """the whole change to the reference — the BSDF accessors, `--gpu[=<device>]` in Options, the `case Options::PT` of
+    make_technique.cpp, the Makefile lines — is integration/reference.patch.  A dry run (`git apply --check`, nothing is written, nothing of the
+    reference is copied) against the reference tree next to this repository must succeed, so the patch cannot rot against the files it edits."""
+    import shutil
+    import subprocess
+    if not shutil.which("git"):
+        pytest.skip("git not available")
+    patch = os.path.join(ROOT, "integration", "reference.patch")
+    r = subprocess.run(["git", "apply", "--check", "--verbose", patch], cwd=REFERENCE, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(patch).read()
+    touched = sorted(set(re.findall(r"^\+\+\+ b/(\S+)", text, flags=re.M)))
+    assert touched == ["BSDF.hpp", "Makefile", "Options.cpp", "Options.hpp", "make_technique.cpp"]
+    # the patch wires up exactly what the adapter offers: constructor arguments in order (+ the device), accessors by name
+    assert "std::make_shared<GpuPathTracing>(" in text and "options.gpu_device);" in text and "#include <GpuPathTracing.hpp>" in text
+    for call, _, _ in ACCESSORS:
+        assert "+  " in text and call.split("->")[1] in text
+    ctor = re.search(r"GpuPathTracing\(([^)]*)\)", open(os.path.join(ROOT, "integration", "GpuPathTracing.hpp")).read()).group(1)
+    names = [a.split("=")[0].strip().split()[-1] for a in ctor.split(",")]
+    assert names[:7] == ["scene", "lights", "roulette", "beta", "max_path", "num_threads", "device"], names  # the order make_technique.cpp passes them in

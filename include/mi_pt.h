@@ -205,6 +205,10 @@ int mi_pt_set_tile_shard(mi_pt_handle* h, uint32_t rank, uint32_t world);
 int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_t camera_id, uint32_t width,
                        uint32_t height, mi_window win, uint32_t spp, uint64_t seed, uint64_t sample_offset,
                        float* rgbn_sum, mi_pt_stats* stats);
+/* Where the last mi_pt_render_multi call of this thread assembled the frame: 1 = on the first handle's device (peer reads of the owners' tiles,
+ * xGMI between GPUs of one node; one copy of the merged frame to the host), 0 = on the host from every device's framebuffer (no peer access, or
+ * MI_PT_MULTI_HOST_MERGE=1), -1 = no call yet.  The in-process form of `master merge` (Options.cpp:1340-1409). */
+int mi_pt_last_multi_merge(void);
 
 /* ------------------------------------------------------------------------------------------
  * Frames in flight — the reference's cadence.  Application::render calls Technique::render ONCE PER SAMPLE

@@ -50,7 +50,9 @@ struct mi_pt_handle {
   bool lds_fits = false;
   double* partial = nullptr; size_t partial_bytes = 0;
   float* d_rgbn = nullptr; size_t rgbn_bytes = 0;
-  float* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned host copy of d_rgbn (mi_pt_render_multi)
+  float* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned host copy of d_rgbn (mi_pt_render_multi, host-side merge)
+  float* d_merge = nullptr; size_t merge_bytes = 0;    // the merged frame on the first handle's device (mi_pt_render_multi, device-side merge)
+  hipEvent_t ev_multi = nullptr;                        // this handle's render of a mi_pt_render_multi call is complete
   unsigned long long* d_counters = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -83,7 +85,30 @@ struct mi_pt_handle {
   mi_pt_launch_info last{};
 };
 
+// mi_pt_render_multi, device-side merge: device 0 assembles the frame from the owners' framebuffers — every 32x32 tile of the window (Technique.cpp:167)
+// read from the device that rendered it, over xGMI when the owners are peers — and only the merged frame crosses PCIe.  A copy, not a sum: the
+// merged frame is bit-identical to a one-device render.  `master merge` (Options.cpp:1340-1409) adds whole images on the host; here nothing overlaps.
+constexpr uint32_t kMaxMergeSources = 16;
+struct MergeSources { const float4* fb[kMaxMergeSources]; };
+__global__ __launch_bounds__(256) void k_merge_tiles(MergeSources src, uint32_t n, float4* __restrict__ out, uint32_t width, uint32_t height,
+                                                    uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t mtx) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= width * height) return;
+  const uint32_t y = i / width, x = i - y * width;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (x >= x0 && x < x0 + w && y >= y0 && y < y0 + h) {
+    const uint32_t owner = (((y - y0) >> 5) * mtx + ((x - x0) >> 5)) % n;
+    const float4* p = src.fb[0];
+#pragma unroll
+    for (uint32_t k = 1; k < kMaxMergeSources; ++k) if (owner == k) p = src.fb[k];
+    v = p[i];
+  }
+  out[i] = v;
+}
+
 namespace {
+
+thread_local int g_last_multi_merge = -1;  // mi_pt_last_multi_merge(): 1 = the last mi_pt_render_multi of this thread merged on the device, 0 = on the host
 
 constexpr uint32_t kFlatLeavesDefault = 24;  // flat leaf list by default up to this many leaf links (the uniform box loop costs ~20 VALU per leaf and ray)
 constexpr size_t kLdsSceneLimit = 52 * 1024;  // LDS bytes per workgroup of the LDS-resident kernels (scene copy + stack + sums): 3 workgroups per CU (160 KB / 3, allocation granules);
@@ -517,6 +542,8 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->h_stage) hipHostFree(h->h_stage);
+  if (h->d_merge) hipFree(h->d_merge);
+  if (h->ev_multi) hipEventDestroy(h->ev_multi);
   if (h->ev2) hipEventDestroy(h->ev2);
   for (auto& bs : h->batches) {
     if (bs.pending_mask && bs.ev_copied) (void)hipEventSynchronize(bs.ev_copied);
@@ -911,15 +938,31 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
   if (uint64_t(win.x0) + win.w > width || uint64_t(win.y0) + win.h > height)
     return fail(MI_ERR_INVALID_ARGUMENT, "window exceeds the image");  // Technique.cpp:318-319 runtime_assert
   const size_t bytes = size_t(width) * height * 16;
-  // 1. every device renders its tiles on its own stream and copies its framebuffer to pinned host memory
+  // Where is the frame put together?  On the first handle's device when it can read every owner's framebuffer (the same device, or a peer: xGMI
+  // between the GPUs of one node), one copy of the merged frame to the host; otherwise — or with MI_PT_MULTI_HOST_MERGE=1 — every framebuffer
+  // goes to pinned host memory and the tiles are assembled there (n x 16 B per pixel over PCIe; the round-2 path).
+  bool device_merge = n_handles <= kMaxMergeSources;
+  if (const char* e = std::getenv("MI_PT_MULTI_HOST_MERGE")) if (std::atoi(e) != 0) device_merge = false;
+  for (uint32_t k = 1; k < n_handles && device_merge; ++k) {
+    if (handles[k]->device == handles[0]->device) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, handles[0]->device, handles[k]->device) != hipSuccess || !can) { device_merge = false; break; }
+    if (hipSetDevice(handles[0]->device) != hipSuccess) { device_merge = false; break; }
+    const hipError_t pe = hipDeviceEnablePeerAccess(handles[k]->device, 0);
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) device_merge = false;
+    (void)hipGetLastError();
+  }
+  // 1. every device renders its tiles on its own stream (host-side merge: and copies its framebuffer to pinned host memory)
   int rc = MI_OK;
   uint32_t launched = 0;
   for (; launched < n_handles && rc == MI_OK; ++launched) {
     mi_pt_handle* h = handles[launched];
     rc = hipSetDevice(h->device) == hipSuccess ? MI_OK : fail(MI_ERR_NO_DEVICE, "hipSetDevice failed");
     if (rc == MI_OK) rc = ensure(reinterpret_cast<void**>(&h->d_rgbn), &h->rgbn_bytes, bytes);
-    if (rc == MI_OK && h->h_stage_bytes < bytes) {
+    if (rc == MI_OK && !device_merge && h->h_stage_bytes < bytes) {
       if (h->h_stage) hipHostFree(h->h_stage);
+  if (h->d_merge) hipFree(h->d_merge);
+  if (h->ev_multi) hipEventDestroy(h->ev_multi);
       h->h_stage = nullptr; h->h_stage_bytes = 0;
       if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), bytes, hipHostMallocDefault) != hipSuccess) rc = fail(MI_ERR_OUT_OF_MEMORY, "pinned host staging buffer");
       else h->h_stage_bytes = bytes;
@@ -929,7 +972,30 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
     h->shard_rank = launched; h->shard_world = n_handles;
     rc = mi_pt_render_device(h, camera_id, width, height, win, spp, seed, sample_offset, h->d_rgbn, nullptr, nullptr);  // asynchronous
     h->shard_rank = saved_rank; h->shard_world = saved_world;
-    if (rc == MI_OK && hipMemcpyAsync(h->h_stage, h->d_rgbn, bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(MI_ERR_NO_DEVICE, "framebuffer copy failed");
+    if (rc == MI_OK && !device_merge && hipMemcpyAsync(h->h_stage, h->d_rgbn, bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(MI_ERR_NO_DEVICE, "framebuffer copy failed");
+    if (rc == MI_OK && device_merge) {
+      if (!h->ev_multi && hipEventCreateWithFlags(&h->ev_multi, hipEventDisableTiming) != hipSuccess) rc = fail(MI_ERR_NO_DEVICE, "event creation failed");
+      if (rc == MI_OK && hipEventRecord(h->ev_multi, h->stream) != hipSuccess) rc = fail(MI_ERR_NO_DEVICE, "event record failed");
+    }
+  }
+  // 1b. device-side merge on the first handle's stream, behind every owner's render; the merged frame goes straight to the caller's buffer
+  if (rc == MI_OK && device_merge) {
+    mi_pt_handle* h0 = handles[0];
+    rc = hipSetDevice(h0->device) == hipSuccess ? MI_OK : fail(MI_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (rc == MI_OK) rc = ensure(reinterpret_cast<void**>(&h0->d_merge), &h0->merge_bytes, bytes);
+    if (rc == MI_OK) {
+      MergeSources src;
+      for (uint32_t k = 0; k < kMaxMergeSources; ++k) src.fb[k] = reinterpret_cast<const float4*>(handles[k < n_handles ? k : 0]->d_rgbn);
+      for (uint32_t k = 1; k < n_handles && rc == MI_OK; ++k)
+        if (hipStreamWaitEvent(h0->stream, handles[k]->ev_multi, 0) != hipSuccess) rc = fail(MI_ERR_NO_DEVICE, "cross-device wait failed");
+      if (rc == MI_OK) {
+        const uint32_t n_px = width * height;
+        hipLaunchKernelGGL(k_merge_tiles, dim3((n_px + 255u) / 256u), dim3(256), 0, h0->stream, src, n_handles, reinterpret_cast<float4*>(h0->d_merge), width, height,
+                           win.x0, win.y0, win.w, win.h, (win.w + 31u) / 32u);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(rgbn_sum, h0->d_merge, bytes, hipMemcpyDeviceToHost, h0->stream) != hipSuccess)
+          rc = fail(MI_ERR_NO_DEVICE, "device-side merge failed");
+      }
+    }
   }
   // 2. wait for every device that was started, also after an error
   mi_pt_stats total; std::memset(&total, 0, sizeof total);
@@ -958,7 +1024,13 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
     if (one.gpu_ms > total.gpu_ms) total.gpu_ms = one.gpu_ms;
   }
   if (rc != MI_OK) return rc;
-  // 3. every 32x32 tile of the window from its owner; everything else is zero
+  if (device_merge) {  // step 2 waited for handles[0]'s stream too: the merged frame is in rgbn_sum
+    g_last_multi_merge = 1;
+    if (stats) *stats = total;
+    return MI_OK;
+  }
+  g_last_multi_merge = 0;
+  // 3. (host-side merge) every 32x32 tile of the window from its owner; everything else is zero
   std::memset(rgbn_sum, 0, bytes);
   const uint32_t mtx = (win.w + 31) / 32, mty = (win.h + 31) / 32;
   for (uint32_t ty = 0; ty < mty; ++ty)
@@ -972,6 +1044,8 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
   if (stats) *stats = total;
   return MI_OK;
 }
+
+int mi_pt_last_multi_merge(void) { return g_last_multi_merge; }
 
 int mi_pt_intersect(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins, const float* directions, mi_surface_point* out_hits,
                     float* out_t, uint32_t* out_prim) {

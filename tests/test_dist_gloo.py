@@ -171,3 +171,42 @@ def test_world2_gloo_merge_equals_single_process(tmp_path):
     np.testing.assert_allclose(t0, single, rtol=1e-6, atol=1e-7)   # FP32 partial sums vs one FP64 accumulation
     first = oracle.Oracle(scene, max_path=4).render_rgbn(24, 24, spp=spp * world, seed=5, sample_offset=0, threads=1)
     np.testing.assert_allclose(np.load(tmp_path / "reduce0.npy"), first, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("rank,local_rank,visible", [(1, 1, 2), (3, 3, 8), (1, 1, 1)])
+def test_bench_rccl_branch_reaches_init_process_group(monkeypatch, rank, local_rank, visible):
+    """the `--backend nccl` branch of bench.py with WORLD_SIZE > 1 has never run anywhere (one GPU per gpurun box).  Its
+    plumbing up to the first collective is checked here without a GPU: RANK / LOCAL_RANK / WORLD_SIZE from the launcher's environment, LOCAL_RANK mapped
+    onto the visible devices (one visible device per rank when the launcher restricts visibility), MASTER_ADDR defaulted to 127.0.0.1, and
+    init_process_group called with backend "nccl" (= RCCL on ROCm), this rank, the world size and the rank's device."""
+    import importlib
+    world = 8 if rank == 3 else 2
+    seen = {}
+
+    class Reached(Exception):
+        pass
+
+    def fake_init(**kw):
+        seen.update(kw)
+        raise Reached()
+
+    monkeypatch.setenv("RANK", str(rank)); monkeypatch.setenv("LOCAL_RANK", str(local_rank)); monkeypatch.setenv("WORLD_SIZE", str(world))
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: visible)
+    chosen = []
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: chosen.append(d))
+    monkeypatch.setattr(dist, "init_process_group", fake_init)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0"])
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    with pytest.raises(Reached):
+        bench.main()
+    dev = local_rank % visible
+    assert chosen == [dev]
+    assert seen["backend"] == "nccl" and seen["rank"] == rank and seen["world_size"] == world and seen["device_id"] == torch.device("cuda", dev)
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1"
+    # a launch whose WORLD_SIZE disagrees with --gpus is refused before anything is initialised
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(SystemExit):
+        bench.main()

@@ -424,11 +424,16 @@ def test_pixel_tile_sharding_is_a_bitwise_partition_of_the_render(cornell, kerne
         pt.bpt_render_rgbn(32, 32, spp=1)
 
 
+@pytest.mark.parametrize("merge", ["device", "host"])
 @pytest.mark.parametrize("kernel", [ma.KERNEL_AUTO, ma.KERNEL_MEGA_GLOBAL, ma.KERNEL_WAVEFRONT])
-def test_one_process_multi_device_render_is_bit_identical(cornell, kernel):
+def test_one_process_multi_device_render_is_bit_identical(cornell, kernel, merge, monkeypatch):
     """mi_pt_render_multi: several handles (one per GPU; here all on this box's only GPU, on their own streams) render the
-    tiles of one frame set concurrently; the merged framebuffer and the summed statistics equal one handle's render."""
+    tiles of one frame set concurrently; the merged framebuffer and the summed statistics equal one handle's render.  The frame is put together
+    on the first handle's device (r03: a gather of every tile from its owner — peer reads over xGMI between GPUs — and ONE copy to the host) or,
+    without peer access / with MI_PT_MULTI_HOST_MERGE=1, on the host from every device's framebuffer: same bits either way."""
     assert ma.device_count() >= 1
+    if merge == "host":
+        monkeypatch.setenv("MI_PT_MULTI_HOST_MERGE", "1")
     pts = [ma.PathTracing(cornell, max_path=8) for _ in range(3)]
     for t in pts:
         t.set_kernel(kernel)
@@ -441,6 +446,7 @@ def test_one_process_multi_device_render_is_bit_identical(cornell, kernel):
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (W, H, win, n)
             assert (st.num_paths, st.num_basic_rays, st.num_shadow_rays, st.numeric_errors) == (rs.num_paths, rs.num_basic_rays, rs.num_shadow_rays, rs.numeric_errors)
             assert kernel == ma.KERNEL_WAVEFRONT or st.gpu_ms > 0
+            assert ma.lib().mi_pt_last_multi_merge() == (1 if merge == "device" else 0)
     own = pts[1].render_rgbn(64, 64, spp=1, seed=1)   # still sharded (1 of 2): the left 32 columns of the upper tile row... belong to rank 0
     assert (own[:32, :32, 3] == 0).all() and (own[:32, 32:, 3] == 1).all()
     with pytest.raises(ma.MiError):

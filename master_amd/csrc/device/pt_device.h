@@ -312,9 +312,11 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
   if (lane < 2u) d.occl[lane] = 0u;
   uint32_t mode = alive ? 1u : 0u;  // 0 idle, 1 own closest-hit ray, 2 a shadow ray of `owner`
   uint32_t owner = lane;
-  f3 co = org, cd = dir;
-  float tmax = __builtin_inff();
-  RayBox rb = QUANT ? make_raybox((co - glo) * gis, cd * gis) : make_raybox(co, cd);
+  // Register diet (r03: the 6-wave budget spilled 18 dwords of path state around this loop, 100 B per lane and trip of scratch traffic through L2):
+  // the walked ray itself is not kept — a leaf re-reads it (own ray: the caller's org / dir; a fetched shadow ray: its parked copy in LDS), the
+  // far end is h.t or 1 by `mode`, and of a closest hit only (t, id, pos) live in the loop: U, V and |den| are formed again for the winner after it.
+  RayBox rb = QUANT ? make_raybox((org - glo) * gis, dir * gis) : make_raybox(org, dir);
+  h.pos = 0xFFFFFFFFu;  // nothing hit yet (h.id is formed after the loop)
   int sp = 0, node = 0;
   for (;;) {
     const uint64_t busy = __ballot(mode != 0u);
@@ -334,10 +336,10 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
 #endif
       if (mode == 0u && rank_i < n_pool) {
         owner = d.mailbox[rank_i];
-        co = F3(d.ray[owner], d.ray[64 + owner], d.ray[128 + owner]);
-        cd = F3(d.ray[192 + owner], d.ray[256 + owner], d.ray[320 + owner]);
-        rb = QUANT ? make_raybox((co - glo) * gis, cd * gis) : make_raybox(co, cd);
-        tmax = 1.0f; mode = 2u; sp = 0; node = 0;
+        const f3 so = F3(d.ray[owner], d.ray[64 + owner], d.ray[128 + owner]);
+        const f3 sd = F3(d.ray[192 + owner], d.ray[256 + owner], d.ray[320 + owner]);
+        rb = QUANT ? make_raybox((so - glo) * gis, sd * gis) : make_raybox(so, sd);
+        mode = 2u; sp = 0; node = 0;
       }
       continue;
     }
@@ -354,6 +356,7 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
 #endif
     if (mode != 0u) {
       bool pop = false;
+      const float tmax = mode == 2u ? 1.0f : h.t;
       if (node >= 0) {
         if (QUANT == 2) {
           // wide quantised node: the (up to) four grandchildren, nearest first, the others pushed farthest first (traverse() above)
@@ -413,6 +416,8 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
         // Embree single-ray Moeller-Trumbore (tri_test above), both ray kinds: a closest-hit ray sees every geometry and keeps the (t, id)
         // minimum; a shadow ray sees mesh geometry only and ends at the first hit with t <= 1
         const uint32_t pos = uint32_t(~node) & kLeafPosMask;  // bit 30 of ~node: pair leaf, the triangle at pos + 1 is this lane's next iteration
+        f3 co = org, cd = dir;
+        if (mode == 2u) { co = F3(d.ray[owner], d.ray[64 + owner], d.ray[128 + owner]); cd = F3(d.ray[192 + owner], d.ray[256 + owner], d.ray[320 + owner]); }
         const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
         const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
         const uint32_t id = __float_as_uint(c.y), gmask = __float_as_uint(c.z);
@@ -431,9 +436,10 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
           const float t = T / absden;
           if (mode == 2u) {
             if (t <= 1.0f) { atomicOr((unsigned int*)&d.occl[owner >> 5], 1u << (owner & 31u)); mode = 0u; pop = false; }
-          } else if (t < h.t || (t == h.t && id < h.id)) {
-            h.t = t; h.u = U; h.v = V; h.den = absden; h.id = id; h.pos = uint32_t(~node) & kLeafPosMask;
-            tmax = t;
+          } else if (t < h.t || (t == h.t && (h.pos == 0xFFFFFFFFu || id < __float_as_uint(tris[3 * h.pos + 2].y)))) {
+            // (t, id) minimum; on an exact tie (rare) the best hit's id is read back.  t == h.t == infinity with nothing hit yet (|den| so
+            // small that T / |den| overflows) is a hit, as in tri_test: its id is smaller than the initial 0xFFFFFFFF
+            h.t = t; h.pos = uint32_t(~node) & kLeafPosMask;
           }
         }
         if ((uint32_t(node) & kLeafPairBit) == 0u && mode != 0u) { node = int((uint32_t(node) | kLeafPairBit) - 1u); pop = false; }  // ~(pos + 1), a single leaf
@@ -444,6 +450,17 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
       }
     }
   }
+  if (alive && h.pos != 0xFFFFFFFFu) {  // id, U, V, |den| of the winner: the leaf's own expressions on the same operands, so the same bits
+    const float4 a = tris[3 * h.pos], b = tris[3 * h.pos + 1], c = tris[3 * h.pos + 2];
+    h.id = __float_as_uint(c.y);
+    const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
+    const f3 ng = cross(e2, e1);
+    const f3 R = cross(v0 - org, dir);
+    const float den = dot(ng, dir);
+    const float sgn = den < 0.0f ? -1.0f : 1.0f;
+    h.u = dot(R, e2) * sgn; h.v = dot(R, e1) * sgn; h.den = fabsf(den);
+  }
+  else h.pos = 0u;
   finish_hit(h);
   const uint32_t word = d.occl[lane >> 5];
   return (word >> (lane & 31u)) & 1u ? 0.0f : 1.0f;

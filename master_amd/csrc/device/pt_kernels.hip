@@ -590,6 +590,10 @@ __global__ __launch_bounds__(kBlock) void k_occluded_flat(SceneView sv, const fl
   out[i] = h.id != 0xFFFFFFFFu ? 0.f : 1.f;
 }
 
+#ifdef MI_ONE_KERNEL
+// register-budget experiments (tools/one_kernel.sh): compile ONE instantiation and stop — seconds instead of minutes
+template __global__ void pt_megakernel<MI_ONE_KERNEL>(const RenderParams p);
+#else
 // ---- host-callable launchers (declared in launch.h) ----
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene) {
   return (lds_scene ? (p.flat_k ? size_t(kFlatLeafF4 * p.flat_k + 18u * p.flat_k + (p.sv.blob_f4 - p.sv.off_mats)) * 16 : size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16)
@@ -707,5 +711,7 @@ hipError_t launch_occluded_flat(const SceneView& sv, const float* table, uint32_
   hipLaunchKernelGGL(k_occluded_flat, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, stream, sv, table, K, k_mesh, n, a, b, out);
   return hipGetLastError();
 }
+
+#endif  // MI_ONE_KERNEL
 
 }  // namespace mi

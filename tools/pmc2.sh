@@ -11,7 +11,7 @@ for set in \
   "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM" \
   "FETCH_SIZE" "WRITE_SIZE" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/pass$i" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-hbm-workload "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || { echo "pass $i failed"; tail -2 "$OUT/pass$i.err"; }
+  rocprofv3 --pmc $set --output-format csv -d "$OUT/pass$i" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-hbm-workload --no-time-to-rmse "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || { echo "pass $i failed"; tail -2 "$OUT/pass$i.err"; }
 done
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections

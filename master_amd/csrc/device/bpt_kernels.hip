@@ -783,10 +783,8 @@ __global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const uint4 a = q4[4 * node + k];
-            const f3 lo = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
-            const f3 hi = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
             float tn;
-            const bool hk = box_test(lo, hi, rb, 1.0f, tn) && int(a.w) != kEmptyLink;
+            const bool hk = wide_child_test(a, rb, 1.0f, tn) && int(a.w) != kEmptyLink;
             t[k] = hk ? tn : __builtin_inff();
             l[k] = int(a.w);
           }

@@ -519,14 +519,23 @@ __global__ void k_collapse4(uint32_t n_nodes, const mi_bvh_node* __restrict__ no
   const bool even = (x + 1 < n_nodes ? flag_scan[x + 1] : flag_scan[n_nodes]) != me;  // exclusive scan: the flag is the difference
   if (!even) return;
   uint4 out[4];
-  for (int k = 0; k < 4; ++k) out[k] = make_uint4(0xFFFFu | (0xFFFFu << 16), 0xFFFFu, 0u, 0x7FFFFFFFu);  // empty: link kEmptyLink
+  for (int k = 0; k < 4; ++k) out[k] = make_uint4(0u, 0u, 0u, 0x7FFFFFFFu);  // empty: link kEmptyLink (the walks test the link)
   const mi_bvh_node n = nodes[x];
   int k = 0;
   auto put = [&](const float* lo, const float* hi, int link) {
+    // centre and half extent of the quantised box (wide_child_test, pt_device.h): c = (lo + hi) / 2 rounded down, e = what covers both ends + 1 cell
     uint4 a;
-    a.x = q_lo(lo[0], lx, ix) | (q_lo(lo[1], ly, iy) << 16);
-    a.y = q_lo(lo[2], lz, iz) | (q_hi(hi[0], lx, ix) << 16);
-    a.z = q_hi(hi[1], ly, iy) | (q_hi(hi[2], lz, iz) << 16);
+    uint32_t c[3], e[3];
+    const float glo[3] = {lx, ly, lz}, gis[3] = {ix, iy, iz};
+    for (int k3 = 0; k3 < 3; ++k3) {
+      const uint32_t ql = q_lo(lo[k3], glo[k3], gis[k3]), qh = q_hi(hi[k3], glo[k3], gis[k3]);
+      c[k3] = (ql + qh) >> 1;
+      const uint32_t ext = (qh - c[k3] > c[k3] - ql ? qh - c[k3] : c[k3] - ql) + 1u;
+      e[k3] = ext > 65535u ? 65535u : ext;
+    }
+    a.x = c[0] | (c[1] << 16);
+    a.y = c[2] | (e[0] << 16);
+    a.z = e[1] | (e[2] << 16);
     a.w = link >= 0 ? flag_scan[link] : uint32_t(link);  // internal grandchildren are even-depth nodes: their record number
     out[k++] = a;
   };

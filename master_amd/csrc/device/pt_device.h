@@ -113,6 +113,21 @@ MI_DEV bool box_test(f3 lo, f3 hi, const RayBox& rb, float tmax, float& tnear) {
   return tn <= fmaf(tf, 1.000002f, rb.slack);
 }
 
+// A child of a wide quantised record (r03): centre and half extent on the 16-bit grid (x = cx | cy << 16, y = cz | ex << 16, z = ey | ez << 16; the
+// half extent rounded up over the quantised box, + 1 cell).  Per axis m = c * inv - org * inv, tnear = m -/+ e * |inv| — three fmas (|inv| is an
+// operand modifier) instead of two fmas, a min and a max: min / max / cmp issue at half the fma rate on gfx950, and the walk of the large scenes is
+// bound by its box tests (profiles/r03/ab_wide8.txt).  No per-ray slack: the extra cell covers the roundings (coordinates <= 65535: every term
+// below 0.04 cell).  Only has to be conservative; hits are the (t, id) minimum whatever is opened.
+MI_DEV bool wide_child_test(const uint4 a, const RayBox& rb, float tmax, float& tnear) {
+  const float cx = float(a.x & 0xFFFFu), cy = float(a.x >> 16), cz = float(a.y & 0xFFFFu);
+  const float ex = float(a.y >> 16), ey = float(a.z & 0xFFFFu), ez = float(a.z >> 16);
+  const float mx = fmaf(cx, rb.inv.x, -rb.oi.x), my = fmaf(cy, rb.inv.y, -rb.oi.y), mz = fmaf(cz, rb.inv.z, -rb.oi.z);
+  const float tn = fmaxf(fmaxf(fmaxf(fmaf(-ex, fabsf(rb.inv.x), mx), fmaf(-ey, fabsf(rb.inv.y), my)), fmaf(-ez, fabsf(rb.inv.z), mz)), 0.0f);
+  const float tf = fminf(fminf(fminf(fmaf(ex, fabsf(rb.inv.x), mx), fmaf(ey, fabsf(rb.inv.y), my)), fmaf(ez, fabsf(rb.inv.z), mz)), tmax);
+  tnear = tn;
+  return tn <= tf;
+}
+
 // Per-lane traversal stack: the first `cap` levels live in LDS (stack[level * kBlock + tid]: consecutive
 // lanes hit consecutive banks); deeper levels — rare, traversal keeps few far children pending — go to a
 // private (scratch) array, so LDS per workgroup stays at `cap` KB however deep the LBVH is.
@@ -182,10 +197,8 @@ MI_DEV void traverse_raw(const float4* __restrict__ sb, const SceneView& sv, Sta
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const uint4 a = q4[4 * node + k];
-          const f3 lo = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
-          const f3 hi = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
           float tn;
-          const bool hk = box_test(lo, hi, rb, h.t, tn) && int(a.w) != kEmptyLink;
+          const bool hk = wide_child_test(a, rb, h.t, tn) && int(a.w) != kEmptyLink;
           t[k] = hk ? tn : __builtin_inff();
           l[k] = int(a.w);
         }
@@ -364,10 +377,8 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const uint4 a = q4[4 * node + k];
-            const f3 lo = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
-            const f3 hi = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
             float tn;
-            const bool hk = box_test(lo, hi, rb, tmax, tn) && int(a.w) != kEmptyLink;
+            const bool hk = wide_child_test(a, rb, tmax, tn) && int(a.w) != kEmptyLink;
             t[k] = hk ? tn : __builtin_inff();
             l[k] = int(a.w);
           }

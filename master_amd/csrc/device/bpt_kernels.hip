@@ -801,23 +801,20 @@ __global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const
             pop = true;
           }
         } else {
-          f3 lo0, hi0, lo1, hi1;
           int l0, l1;
+          float tn0, tn1;
+          bool h0, h1;
           if (QN) {
             const uint4 a = qn[2 * node], b = qn[2 * node + 1];
-            lo0 = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
-            hi0 = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
-            lo1 = F3(float(b.x & 0xFFFFu), float(b.x >> 16), float(b.y & 0xFFFFu));
-            hi1 = F3(float(b.y >> 16), float(b.z & 0xFFFFu), float(b.z >> 16));
             l0 = int(a.w); l1 = int(b.w);
+            h0 = wide_child_test(a, rb, 1.0f, tn0);
+            h1 = wide_child_test(b, rb, 1.0f, tn1);
           } else {
             const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
-            lo0 = xyz(n0); hi0 = xyz(n1); lo1 = xyz(n2); hi1 = xyz(n3);
             l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
+            if (NS == 5) { h0 = ce_box_test(xyz(n0), xyz(n1), rb, 1.0f, tn0); h1 = ce_box_test(xyz(n2), xyz(n3), rb, 1.0f, tn1); }  // the LDS copy
+            else { h0 = box_test(xyz(n0), xyz(n1), rb, 1.0f, tn0); h1 = box_test(xyz(n2), xyz(n3), rb, 1.0f, tn1); }
           }
-          float tn0, tn1;
-          const bool h0 = box_test(lo0, hi0, rb, 1.0f, tn0);
-          const bool h1 = box_test(lo1, hi1, rb, 1.0f, tn1);
           if (h0 && h1) {
             const bool sw = tn1 < tn0;
             stack.push(sp, uint32_t(sw ? l0 : l1));

@@ -488,15 +488,19 @@ __global__ void k_quantize(uint32_t n_nodes, const mi_bvh_node* __restrict__ nod
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   const mi_bvh_node n = nodes[i];
-  uint4 a, b;
-  a.x = q_lo(n.lo0[0], lx, ix) | (q_lo(n.lo0[1], ly, iy) << 16);
-  a.y = q_lo(n.lo0[2], lz, iz) | (q_hi(n.hi0[0], lx, ix) << 16);
-  a.z = q_hi(n.hi0[1], ly, iy) | (q_hi(n.hi0[2], lz, iz) << 16);
-  a.w = uint32_t(n.link0);
-  b.x = q_lo(n.lo1[0], lx, ix) | (q_lo(n.lo1[1], ly, iy) << 16);
-  b.y = q_lo(n.lo1[2], lz, iz) | (q_hi(n.hi1[0], lx, ix) << 16);
-  b.z = q_hi(n.hi1[1], ly, iy) | (q_hi(n.hi1[2], lz, iz) << 16);
-  b.w = uint32_t(n.link1);
+  // each child: centre and half extent of its quantised box (+ 1 cell), the encoding of the wide records (k_collapse4; wide_child_test, pt_device.h)
+  auto enc = [&](const float* lo, const float* hi, int link) {
+    uint32_t c[3], e[3];
+    const float glo[3] = {lx, ly, lz}, gis[3] = {ix, iy, iz};
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t ql = q_lo(lo[k], glo[k], gis[k]), qh = q_hi(hi[k], glo[k], gis[k]);
+      c[k] = (ql + qh) >> 1;
+      const uint32_t ext = (qh - c[k] > c[k] - ql ? qh - c[k] : c[k] - ql) + 1u;
+      e[k] = ext > 65535u ? 65535u : ext;
+    }
+    return make_uint4(c[0] | (c[1] << 16), c[2] | (e[0] << 16), e[1] | (e[2] << 16), uint32_t(link));
+  };
+  const uint4 a = enc(n.lo0, n.hi0, n.link0), b = enc(n.lo1, n.hi1, n.link1);
   qnodes[2 * size_t(i)] = a;
   qnodes[2 * size_t(i) + 1] = b;
 }

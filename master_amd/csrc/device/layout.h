@@ -39,6 +39,7 @@ struct SceneView {
   const uint4* qnodes4;
   float grid_lo[3];
   float grid_inv_step[3];  // cells per world unit
+  float box_pad;           // 2^-20 of the largest |coordinate| of the scene box and the cameras: absolute padding of centre / half-extent boxes (LDS node copy, flat leaf table)
 };
 
 struct DevLight {  // 6 float4

@@ -76,7 +76,18 @@ MI_DEV bool tri_test(const float4* __restrict__ tris, uint32_t pos, f3 org, f3 d
 MI_DEV uint32_t lds_scene_f4(const SceneView& sv) { return sv.blob_f4 + sv.n_nodes + sv.n_tris; }
 MI_DEV void stage_scene_to_lds(float4* __restrict__ smem, SceneView& sv, uint32_t tid) {
   const uint32_t o_tris = sv.n_nodes * 5u, o_shade = o_tris + sv.n_tris * 3u, o_rest = o_shade + sv.n_tris * 9u;
-  for (uint32_t i = tid; i < sv.n_nodes * 4u; i += kBlock) smem[(i >> 2) * 5u + (i & 3u)] = sv.blob[sv.off_nodes + i];
+  // nodes: each child box becomes centre + half extent (ce_box_test below: three fmas per axis, no min / max); the half extent covers the box from the
+  // rounded centre, + 2^-20 relative + sv.box_pad (2^-20 of the largest coordinate of the scene and its cameras: the roundings of the test for rays
+  // that start within those bounds — every path ray does).  The links keep their places (n0.w, n1.w); parent / reserved ride along in n2.w, n3.w.
+  for (uint32_t i = tid; i < sv.n_nodes * 2u; i += kBlock) {
+    const uint32_t n = i >> 1, c = i & 1u;
+    const float4 lo = sv.blob[sv.off_nodes + 4u * n + 2u * c], hi = sv.blob[sv.off_nodes + 4u * n + 2u * c + 1u];
+    const f3 ctr = (xyz(lo) + xyz(hi)) * 0.5f;
+    const f3 up = xyz(hi) - ctr, dn = ctr - xyz(lo);
+    const f3 ext = F3(fmaf(fmaxf(up.x, dn.x), 1.000001f, sv.box_pad), fmaf(fmaxf(up.y, dn.y), 1.000001f, sv.box_pad), fmaf(fmaxf(up.z, dn.z), 1.000001f, sv.box_pad));
+    smem[n * 5u + 2u * c] = make_float4(ctr.x, ctr.y, ctr.z, lo.w);
+    smem[n * 5u + 2u * c + 1u] = make_float4(ext.x, ext.y, ext.z, hi.w);
+  }
   for (uint32_t i = tid; i < sv.n_tris * 3u; i += kBlock) smem[o_tris + i] = sv.blob[sv.off_tris + i];
   for (uint32_t i = tid; i < sv.n_tris * 8u; i += kBlock) smem[o_shade + (i >> 3) * 9u + (i & 7u)] = sv.blob[sv.off_shade + i];
   for (uint32_t i = tid; i < sv.blob_f4 - sv.off_mats; i += kBlock) smem[o_rest + i] = sv.blob[sv.off_mats + i];
@@ -101,6 +112,15 @@ MI_DEV RayBox make_raybox(f3 org, f3 dir) {
   r.oi = org * r.inv;
   r.slack = (fabsf(r.oi.x) + fabsf(r.oi.y) + fabsf(r.oi.z)) * 2.5e-7f;
   return r;
+}
+
+// centre / half-extent form for the node copies in LDS (stage_scene_to_lds): the padding of the half extent replaces the slack term
+MI_DEV bool ce_box_test(f3 c, f3 e, const RayBox& rb, float tmax, float& tnear) {
+  const float mx = fmaf(c.x, rb.inv.x, -rb.oi.x), my = fmaf(c.y, rb.inv.y, -rb.oi.y), mz = fmaf(c.z, rb.inv.z, -rb.oi.z);
+  const float tn = fmaxf(fmaxf(fmaxf(fmaf(-e.x, fabsf(rb.inv.x), mx), fmaf(-e.y, fabsf(rb.inv.y), my)), fmaf(-e.z, fabsf(rb.inv.z), mz)), 0.0f);
+  const float tf = fminf(fminf(fminf(fmaf(e.x, fabsf(rb.inv.x), mx), fmaf(e.y, fabsf(rb.inv.y), my)), fmaf(e.z, fabsf(rb.inv.z), mz)), tmax);
+  tnear = tn;
+  return tn <= tf;
 }
 
 MI_DEV bool box_test(f3 lo, f3 hi, const RayBox& rb, float tmax, float& tnear) {
@@ -232,24 +252,21 @@ MI_DEV void traverse_raw(const float4* __restrict__ sb, const SceneView& sv, Sta
   }
   for (;;) {
     if (node >= 0) {
-      f3 lo0, hi0, lo1, hi1;
       int l0, l1;
-      if (QUANT) {
+      float tn0, tn1;
+      bool h0, h1;
+      if (QUANT) {  // quantised binary node: two children as centre + half extent on the grid (wide_child_test)
         const uint4 a = qn[2 * node], b = qn[2 * node + 1];
-        lo0 = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
-        hi0 = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
-        lo1 = F3(float(b.x & 0xFFFFu), float(b.x >> 16), float(b.y & 0xFFFFu));
-        hi1 = F3(float(b.y >> 16), float(b.z & 0xFFFFu), float(b.z >> 16));
         l0 = int(a.w); l1 = int(b.w);
+        h0 = wide_child_test(a, rb, h.t, tn0);
+        h1 = wide_child_test(b, rb, h.t, tn1);
       } else {
         const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
-        lo0 = xyz(n0); hi0 = xyz(n1); lo1 = xyz(n2); hi1 = xyz(n3);
         l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
+        if (NS == 5) { h0 = ce_box_test(xyz(n0), xyz(n1), rb, h.t, tn0); h1 = ce_box_test(xyz(n2), xyz(n3), rb, h.t, tn1); }  // the LDS copy
+        else { h0 = box_test(xyz(n0), xyz(n1), rb, h.t, tn0); h1 = box_test(xyz(n2), xyz(n3), rb, h.t, tn1); }
       }
       if (COUNT) { ++vis->nodes; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[0], 1u); }
-      float tn0, tn1;
-      const bool h0 = box_test(lo0, hi0, rb, h.t, tn0);
-      const bool h1 = box_test(lo1, hi1, rb, h.t, tn1);
       if (h0 && h1) {
         const bool sw = tn1 < tn0;
         stack.push(sp, uint32_t(sw ? l0 : l1));
@@ -395,23 +412,20 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
             pop = true;
           }
         } else {
-          f3 lo0, hi0, lo1, hi1;
           int l0, l1;
+          float tn0, tn1;
+          bool h0, h1;
           if (QUANT) {
             const uint4 a = qn[2 * node], b = qn[2 * node + 1];
-            lo0 = F3(float(a.x & 0xFFFFu), float(a.x >> 16), float(a.y & 0xFFFFu));
-            hi0 = F3(float(a.y >> 16), float(a.z & 0xFFFFu), float(a.z >> 16));
-            lo1 = F3(float(b.x & 0xFFFFu), float(b.x >> 16), float(b.y & 0xFFFFu));
-            hi1 = F3(float(b.y >> 16), float(b.z & 0xFFFFu), float(b.z >> 16));
             l0 = int(a.w); l1 = int(b.w);
+            h0 = wide_child_test(a, rb, tmax, tn0);
+            h1 = wide_child_test(b, rb, tmax, tn1);
           } else {
             const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
-            lo0 = xyz(n0); hi0 = xyz(n1); lo1 = xyz(n2); hi1 = xyz(n3);
             l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
+            if (NS == 5) { h0 = ce_box_test(xyz(n0), xyz(n1), rb, tmax, tn0); h1 = ce_box_test(xyz(n2), xyz(n3), rb, tmax, tn1); }  // the LDS copy
+            else { h0 = box_test(xyz(n0), xyz(n1), rb, tmax, tn0); h1 = box_test(xyz(n2), xyz(n3), rb, tmax, tn1); }
           }
-          float tn0, tn1;
-          const bool h0 = box_test(lo0, hi0, rb, tmax, tn0);
-          const bool h1 = box_test(lo1, hi1, rb, tmax, tn1);
           if (h0 && h1) {
             const bool sw = tn1 < tn0;
             stack.push(sp, uint32_t(sw ? l0 : l1));

@@ -110,7 +110,8 @@ namespace {
 
 thread_local int g_last_multi_merge = -1;  // mi_pt_last_multi_merge(): 1 = the last mi_pt_render_multi of this thread merged on the device, 0 = on the host
 
-constexpr uint32_t kFlatLeavesDefault = 24;  // flat leaf list by default up to this many leaf links (the uniform box loop costs ~20 VALU per leaf and ray)
+constexpr uint32_t kFlatLeavesDefault = 24;  // flat leaf list by default up to this many leaf links (the uniform box loop costs ~14 VALU per leaf and ray)
+constexpr uint32_t kFlatLeavesMin = 8;       // ... and from this many on: a tree over fewer leaves hardly diverges (profiles/r03/flat_vs_tree_small_scenes.txt: -3..-9 % at 2-7 leaves)
 constexpr size_t kLdsSceneLimit = 52 * 1024;  // LDS bytes per workgroup of the LDS-resident kernels (scene copy + stack + sums): 3 workgroups per CU (160 KB / 3, allocation granules);
                                               // r02, tests/tools/lds_limit.py: 114 triangles (51 KB) LDS 11 107 vs HBM 9 566 Msamples/s, 144 triangles (63 KB, 2 per CU) 7 763 vs 8 763
 
@@ -185,7 +186,7 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   {  // flat leaf list (r03): LDS-resident scenes of at most kFlatLeavesDefault leaf links; MI_PT_FLAT=0/1 overrides (1: up to kFlatMaxLeaves)
     const char* f = std::getenv("MI_PT_FLAT");
     const char* d = std::getenv("MI_PT_DYN");  // an explicit MI_PT_DYN=1 asks for the dynamic-fetch tree walk (A/B, parity tests)
-    const bool want = f ? std::atoi(f) != 0 : (h->flat_k <= kFlatLeavesDefault && !(d && std::atoi(d) != 0));
+    const bool want = f ? std::atoi(f) != 0 : (h->flat_k >= kFlatLeavesMin && h->flat_k <= kFlatLeavesDefault && !(d && std::atoi(d) != 0));
     p.flat_table = h->flat_table; p.flat_k = 0; p.flat_k_mesh = 0;
     if (want && h->flat_k && use_lds_scene(h) && h->kernel_choice != MI_PT_KERNEL_WAVEFRONT) { p.flat_k = h->flat_k; p.flat_k_mesh = h->flat_k_mesh; p.stack_entries = 0; }
   }
@@ -383,6 +384,13 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     HIP_TRY(mi::quantize_nodes(n_nodes, reinterpret_cast<const mi_bvh_node*>(h->blob + sv.off_nodes), h->qnodes, h->qnodes4, h->sv.grid_lo, h->sv.grid_inv_step, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->sv.qnodes = h->qnodes; h->sv.qnodes4 = h->qnodes4;
+    {  // absolute padding of centre / half-extent boxes (pt_device.h ce_box_test, traverse_flat): rays start within the scene box or at a camera
+      double amax = 0.0;
+      for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(double(h->info.scene_lo[a])), std::fabs(double(h->info.scene_hi[a]))));
+      for (const mi_camera& cam : s.cameras) for (int a = 0; a < 3; ++a) amax = std::max(amax, std::fabs(double(cam.position[a])));
+      h->sv.box_pad = float(amax * 0x1p-20 + 1e-30);
+      h->flat_amax = float(amax);
+    }
     // flat leaf list (small scenes): the box and the link of every leaf link of the tree, pair leaves counting once; the leaves that hold a
     // mesh triangle come first (shadow rays test only those, Scene.cpp:42,173)
     if (n_nodes >= 1u && n_nodes <= 2u * mi::kFlatMaxLeaves) {

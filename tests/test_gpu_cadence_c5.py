@@ -264,7 +264,7 @@ def test_flat_leaf_list_is_bit_identical_per_path(monkeypatch, name, beta):
     assert np.isclose(b[0], orad, rtol=0, atol=0, equal_nan=True).all() and np.array_equal(b[1], ocnt)
     monkeypatch.delenv("MI_PT_FLAT")
     pt.render_rgbn(w, h, spp=2, seed=1)
-    assert (pt.last_launch().flat_leaves != 0) == (b[5] <= 24)
+    assert (pt.last_launch().flat_leaves != 0) == (8 <= b[5] <= 24)
 
 
 @pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxPhong", "TestCaseFurnace", "TestCase0", "DoubleLight", "TestCase14", "LightOverBox", "soup31"])
@@ -276,6 +276,7 @@ def test_flat_leaf_list_hooks_on_adversarial_rays(monkeypatch, name):
     s = sb.random_soup(int(name[4:]), seed=5) if name.startswith("soup") else load_scene(name)
     monkeypatch.setenv("MI_PT_INTERSECT_FLAT", "1")
     pt, orc = ma.PathTracing(s), oracle.Oracle(s)
+    monkeypatch.setenv("MI_PT_FLAT", "1")
     pt.render_rgbn(8, 8, spp=1, seed=1)
     assert pt.last_launch().flat_leaves > 0
     rng = np.random.default_rng(9)

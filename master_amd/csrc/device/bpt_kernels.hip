@@ -812,8 +812,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const
           } else {
             const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
             l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
-            if (NS == 5) { h0 = ce_box_test(xyz(n0), xyz(n1), rb, 1.0f, tn0); h1 = ce_box_test(xyz(n2), xyz(n3), rb, 1.0f, tn1); }  // the LDS copy
-            else { h0 = box_test(xyz(n0), xyz(n1), rb, 1.0f, tn0); h1 = box_test(xyz(n2), xyz(n3), rb, 1.0f, tn1); }
+            h0 = ce_box_test(xyz(n0), xyz(n1), rb, 1.0f, tn0); h1 = ce_box_test(xyz(n2), xyz(n3), rb, 1.0f, tn1);  // QN == 0: the LDS copy (centre + half extent)
           }
           if (h0 && h1) {
             const bool sw = tn1 < tn0;

@@ -682,6 +682,25 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
   return hipSuccess;
 }
 
+// centre / half-extent copy of the full-precision nodes (ce_box_test<SLACK>, pt_device.h): half extent from the rounded centre, + 2^-20 relative
+// + 2^-21 of the box's own largest coordinate (the roundings of c * inv and e * |inv|; the origin's share is the test's per-ray slack)
+__global__ void k_ce_nodes(uint32_t n_nodes, const float4* __restrict__ nodes, float4* __restrict__ out, float) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes * 2u) return;
+  const uint32_t n = i >> 1, c = i & 1u;
+  const float4 lo = nodes[4u * n + 2u * c], hi = nodes[4u * n + 2u * c + 1u];
+  const float cx = (lo.x + hi.x) * 0.5f, cy = (lo.y + hi.y) * 0.5f, cz = (lo.z + hi.z) * 0.5f;
+  const float px = fmaxf(fabsf(lo.x), fabsf(hi.x)) * 0x1p-21f, py = fmaxf(fabsf(lo.y), fabsf(hi.y)) * 0x1p-21f, pz = fmaxf(fabsf(lo.z), fabsf(hi.z)) * 0x1p-21f;
+  const float ex = fmaf(fmaxf(hi.x - cx, cx - lo.x), 1.000001f, px), ey = fmaf(fmaxf(hi.y - cy, cy - lo.y), 1.000001f, py), ez = fmaf(fmaxf(hi.z - cz, cz - lo.z), 1.000001f, pz);
+  out[4u * n + 2u * c] = make_float4(cx, cy, cz, lo.w);
+  out[4u * n + 2u * c + 1u] = make_float4(ex, ey, ez, hi.w);
+}
+hipError_t ce_nodes(uint32_t n_nodes, const float4* nodes, float4* out, float pad, hipStream_t stream) {
+  if (n_nodes == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_ce_nodes, dim3((2u * n_nodes + 255u) / 256u), dim3(256), 0, stream, n_nodes, nodes, out, pad);
+  return hipGetLastError();
+}
+
 hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, uint4* qnodes4, const float lo[3], const float inv_step[3],
                           hipStream_t stream) {
   if (n_nodes == 0) return hipSuccess;

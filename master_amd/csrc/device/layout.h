@@ -37,6 +37,8 @@ struct SceneView {
   // wide quantised nodes, indexed like the BVH2 nodes (only even-depth entries are valid): 4 x (child box as 6 x u16 + link),
   // the grandchildren of the BVH2 node — 64 B per visited node, half as many dependent fetches per ray
   const uint4* qnodes4;
+  // full-precision nodes as centre + half extent (scenes the 16-bit grid is too coarse for; same layout as the blob's nodes: 4 float4, links in n0.w / n1.w)
+  const float4* ce_nodes;
   float grid_lo[3];
   float grid_inv_step[3];  // cells per world unit
   float box_pad;           // 2^-20 of the largest |coordinate| of the scene box and the cameras: absolute padding of centre / half-extent boxes (LDS node copy, flat leaf table)

@@ -114,13 +114,16 @@ MI_DEV RayBox make_raybox(f3 org, f3 dir) {
   return r;
 }
 
-// centre / half-extent form for the node copies in LDS (stage_scene_to_lds): the padding of the half extent replaces the slack term
+// centre / half-extent form for the node copies: in LDS (stage_scene_to_lds) the padding of the half extent replaces the slack term; the copy read
+// from HBM (sv.ce_nodes, SLACK) pads each box by 2^-21 of its own coordinates only — a scene whose far-away lights stretch its box (MetalRings: 400
+// units around 0.1-unit triangles) must not pay for them in every leaf box — and keeps the per-ray slack for the origin's share of the rounding.
+template <bool SLACK = false>
 MI_DEV bool ce_box_test(f3 c, f3 e, const RayBox& rb, float tmax, float& tnear) {
   const float mx = fmaf(c.x, rb.inv.x, -rb.oi.x), my = fmaf(c.y, rb.inv.y, -rb.oi.y), mz = fmaf(c.z, rb.inv.z, -rb.oi.z);
   const float tn = fmaxf(fmaxf(fmaxf(fmaf(-e.x, fabsf(rb.inv.x), mx), fmaf(-e.y, fabsf(rb.inv.y), my)), fmaf(-e.z, fabsf(rb.inv.z), mz)), 0.0f);
   const float tf = fminf(fminf(fminf(fmaf(e.x, fabsf(rb.inv.x), mx), fmaf(e.y, fabsf(rb.inv.y), my)), fmaf(e.z, fabsf(rb.inv.z), mz)), tmax);
   tnear = tn;
-  return tn <= tf;
+  return SLACK ? tn <= fmaf(tf, 1.000002f, rb.slack) : tn <= tf;
 }
 
 MI_DEV bool box_test(f3 lo, f3 hi, const RayBox& rb, float tmax, float& tnear) {
@@ -138,6 +141,8 @@ MI_DEV bool box_test(f3 lo, f3 hi, const RayBox& rb, float tmax, float& tnear) {
 // operand modifier) instead of two fmas, a min and a max: min / max / cmp issue at half the fma rate on gfx950, and the walk of the large scenes is
 // bound by its box tests (profiles/r03/ab_wide8.txt).  No per-ray slack: the extra cell covers the roundings (coordinates <= 65535: every term
 // below 0.04 cell).  Only has to be conservative; hits are the (t, id) minimum whatever is opened.
+// FAR (the parity hooks, whose callers may pass a point anywhere): + the per-ray slack, which grows with |org * inv| and covers origins far outside the grid.
+template <bool FAR = false>
 MI_DEV bool wide_child_test(const uint4 a, const RayBox& rb, float tmax, float& tnear) {
   const float cx = float(a.x & 0xFFFFu), cy = float(a.x >> 16), cz = float(a.y & 0xFFFFu);
   const float ex = float(a.y >> 16), ey = float(a.z & 0xFFFFu), ez = float(a.z >> 16);
@@ -145,7 +150,7 @@ MI_DEV bool wide_child_test(const uint4 a, const RayBox& rb, float tmax, float& 
   const float tn = fmaxf(fmaxf(fmaxf(fmaf(-ex, fabsf(rb.inv.x), mx), fmaf(-ey, fabsf(rb.inv.y), my)), fmaf(-ez, fabsf(rb.inv.z), mz)), 0.0f);
   const float tf = fminf(fminf(fminf(fmaf(ex, fabsf(rb.inv.x), mx), fmaf(ey, fabsf(rb.inv.y), my)), fmaf(ez, fabsf(rb.inv.z), mz)), tmax);
   tnear = tn;
-  return tn <= tf;
+  return FAR ? tn <= fmaf(tf, 1.000002f, rb.slack) : tn <= tf;
 }
 
 // Per-lane traversal stack: the first `cap` levels live in LDS (stack[level * kBlock + tid]: consecutive
@@ -189,10 +194,11 @@ struct Visits { uint32_t nodes, tris; uint32_t* wave_iters; };  // wave_iters: L
 
 // NS = node stride in float4 units: 4 in HBM; the LDS copy pads nodes to 5 (80 B) so that lanes reading the same field of
 // different nodes spread over all 32 banks instead of 2 groups of 4 (64 B = 16 banks: every other node collides).
-template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, bool MASKED = true, class Stack = TravStack>
+template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, bool MASKED = true, bool FAR = false, class Stack = TravStack>
 MI_DEV void traverse_raw(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 org, f3 dir,
                          uint32_t ray_mask, Hit& h, Visits* vis) {
-  const float4* nodes = sb + sv.off_nodes;
+  // full-precision nodes read from HBM (NS == 4, scenes the 16-bit grid is too coarse for): the centre / half-extent copy of the tree (sv.ce_nodes)
+  const float4* nodes = (QUANT == 0 && NS == 4) ? sv.ce_nodes : sb + sv.off_nodes;
   const float4* tris = sb + sv.off_tris;
   if (sv.n_nodes == 0) {
     if (COUNT) ++vis->tris;
@@ -218,7 +224,7 @@ MI_DEV void traverse_raw(const float4* __restrict__ sb, const SceneView& sv, Sta
         for (int k = 0; k < 4; ++k) {
           const uint4 a = q4[4 * node + k];
           float tn;
-          const bool hk = wide_child_test(a, rb, h.t, tn) && int(a.w) != kEmptyLink;
+          const bool hk = wide_child_test<FAR>(a, rb, h.t, tn) && int(a.w) != kEmptyLink;
           t[k] = hk ? tn : __builtin_inff();
           l[k] = int(a.w);
         }
@@ -258,13 +264,12 @@ MI_DEV void traverse_raw(const float4* __restrict__ sb, const SceneView& sv, Sta
       if (QUANT) {  // quantised binary node: two children as centre + half extent on the grid (wide_child_test)
         const uint4 a = qn[2 * node], b = qn[2 * node + 1];
         l0 = int(a.w); l1 = int(b.w);
-        h0 = wide_child_test(a, rb, h.t, tn0);
-        h1 = wide_child_test(b, rb, h.t, tn1);
+        h0 = wide_child_test<FAR>(a, rb, h.t, tn0);
+        h1 = wide_child_test<FAR>(b, rb, h.t, tn1);
       } else {
         const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
         l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
-        if (NS == 5) { h0 = ce_box_test(xyz(n0), xyz(n1), rb, h.t, tn0); h1 = ce_box_test(xyz(n2), xyz(n3), rb, h.t, tn1); }  // the LDS copy
-        else { h0 = box_test(xyz(n0), xyz(n1), rb, h.t, tn0); h1 = box_test(xyz(n2), xyz(n3), rb, h.t, tn1); }
+        h0 = ce_box_test<NS == 4>(xyz(n0), xyz(n1), rb, h.t, tn0); h1 = ce_box_test<NS == 4>(xyz(n2), xyz(n3), rb, h.t, tn1);  // LDS copy or sv.ce_nodes: centre + half extent
       }
       if (COUNT) { ++vis->nodes; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[0], 1u); }
       if (h0 && h1) {
@@ -332,7 +337,7 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
                           , uint32_t* dyn_stats  // wave-uniform: [0] loop iterations, [1] node bodies, [2] leaf bodies, [3] refills, [4] rays fetched
 #endif
 ) {
-  const float4* nodes = sb + sv.off_nodes;
+  const float4* nodes = (QUANT == 0 && NS == 4) ? sv.ce_nodes : sb + sv.off_nodes;  // traverse_raw
   const float4* tris = sb + sv.off_tris;
   const uint4* __restrict__ qn = sv.qnodes;
   const uint4* __restrict__ q4 = sv.qnodes4;
@@ -423,8 +428,7 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
           } else {
             const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
             l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
-            if (NS == 5) { h0 = ce_box_test(xyz(n0), xyz(n1), rb, tmax, tn0); h1 = ce_box_test(xyz(n2), xyz(n3), rb, tmax, tn1); }  // the LDS copy
-            else { h0 = box_test(xyz(n0), xyz(n1), rb, tmax, tn0); h1 = box_test(xyz(n2), xyz(n3), rb, tmax, tn1); }
+            h0 = ce_box_test<NS == 4>(xyz(n0), xyz(n1), rb, tmax, tn0); h1 = ce_box_test<NS == 4>(xyz(n2), xyz(n3), rb, tmax, tn1);  // LDS copy or sv.ce_nodes
           }
           if (h0 && h1) {
             const bool sw = tn1 < tn0;
@@ -594,10 +598,10 @@ MI_DEV void traverse_flat(const float4* __restrict__ leaves, cfloat* __restrict_
   }
 }
 
-template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, bool MASKED = true, class Stack = TravStack>
+template <bool ANY, bool COUNT = false, int QUANT = 0, int NS = 4, bool MASKED = true, bool FAR = false, class Stack = TravStack>
 MI_DEV void traverse(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 org, f3 dir,
                      uint32_t ray_mask, Hit& h, Visits* vis = nullptr) {
-  traverse_raw<ANY, COUNT, QUANT, NS, MASKED>(sb, sv, stack, org, dir, ray_mask, h, vis);
+  traverse_raw<ANY, COUNT, QUANT, NS, MASKED, FAR>(sb, sv, stack, org, dir, ray_mask, h, vis);
   if (!ANY) finish_hit(h);
 }
 
@@ -638,14 +642,14 @@ MI_DEV f3 nudge(f3 position, f3 gnormal, f3 dir) {
 }
 
 // Scene::occluded (Scene.cpp:151-180): 1 = visible.
-template <bool COUNT = false, int QUANT = 0, int NS = 4, class Stack = TravStack>
+template <bool COUNT = false, int QUANT = 0, int NS = 4, bool FAR = false, class Stack = TravStack>
 MI_DEV float occluded(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, f3 opos, f3 ognormal, f3 tpos,
                       f3 tgnormal, Visits* vis = nullptr) {
   const f3 direction = tpos - opos;  // Scene.cpp:153 normalises; only signs are used
   const f3 ao = opos + (ognormal * (dot(ognormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   const f3 at = tpos + (tgnormal * (dot(tgnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   Hit h; h.t = 1.0f; h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-  traverse<true, COUNT, QUANT, NS>(sb, sv, stack, ao, at - ao, 1u << MI_ENTITY_MESH, h, vis);
+  traverse<true, COUNT, QUANT, NS, true, FAR>(sb, sv, stack, ao, at - ao, 1u << MI_ENTITY_MESH, h, vis);
   return h.id != 0xFFFFFFFFu ? 0.f : 1.f;
 }
 

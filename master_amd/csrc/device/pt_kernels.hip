@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneView sv, uint32_t sta
   const f3 dir = F3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
   const f3 org = nudge(pos, gn, dir);
   Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-  traverse<false, false, QN>(sv.blob, sv, stack, org, dir, 0xFFFFFFFFu, h);
+  traverse<false, false, QN, 4, true, true>(sv.blob, sv, stack, org, dir, 0xFFFFFFFFu, h);  // FAR: a caller's point may lie anywhere
   if (out_t) out_t[i] = h.t;
   if (out_prim) out_prim[i] = h.id;
   if (out_hits) {
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(SceneView sv, uint32_t stac
   stack.cap = stack_entries;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  out[i] = occluded<false, QN>(sv.blob, sv, stack, F3(a[i].position[0], a[i].position[1], a[i].position[2]),
+  out[i] = occluded<false, QN, 4, true>(sv.blob, sv, stack, F3(a[i].position[0], a[i].position[1], a[i].position[2]),
                     F3(a[i].gnormal[0], a[i].gnormal[1], a[i].gnormal[2]), F3(b[i].position[0], b[i].position[1], b[i].position[2]),
                     F3(b[i].gnormal[0], b[i].gnormal[1], b[i].gnormal[2]));
 }

@@ -33,6 +33,7 @@ struct mi_pt_handle {
   float4* blob = nullptr;
   uint4* qnodes = nullptr;
   uint4* qnodes4 = nullptr;
+  float4* ce_nodes = nullptr;       // centre / half-extent copy of the full-precision nodes (kernels that read them from HBM: scenes the 16-bit grid is too coarse for)
   float* flat_table = nullptr; uint32_t flat_k = 0, flat_k_mesh = 0; float flat_amax = 0.0f;  // flat_amax: largest |coordinate| the padding of the table's boxes covers  // flat leaf list of small scenes (traverse_flat, pt_device.h): leaf boxes + links, mesh leaves first
   int2* plain_links = nullptr;    // the builder's links of every node in Morton positions (mi_pt_bvh_download); the blob's nodes carry pair leaves
   bool float_nodes = false;        // HBM-resident kernels read the full-precision nodes: the 16-bit grid is too coarse for this scene
@@ -391,6 +392,11 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
       h->sv.box_pad = float(amax * 0x1p-20 + 1e-30);
       h->flat_amax = float(amax);
     }
+    // every scene gets the copy (64 B per node): the instrumented / list variants of small scenes read full-precision nodes from HBM too
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ce_nodes), size_t(n_nodes ? n_nodes : 1) * 64));
+    HIP_TRY(mi::ce_nodes(n_nodes, h->blob + sv.off_nodes, h->ce_nodes, h->sv.box_pad, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->sv.ce_nodes = h->ce_nodes;
     // flat leaf list (small scenes): the box and the link of every leaf link of the tree, pair leaves counting once; the leaves that hold a
     // mesh triangle come first (shadow rays test only those, Scene.cpp:42,173)
     if (n_nodes >= 1u && n_nodes <= 2u * mi::kFlatMaxLeaves) {
@@ -534,6 +540,7 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->blob) hipFree(h->blob);
   if (h->qnodes) hipFree(h->qnodes);
   if (h->qnodes4) hipFree(h->qnodes4);
+  if (h->ce_nodes) hipFree(h->ce_nodes);
   if (h->plain_links) hipFree(h->plain_links);
   if (h->flat_table) hipFree(h->flat_table);
   if (h->d_sorted_tri) hipFree(h->d_sorted_tri);
@@ -723,7 +730,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
     li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = p.dyn_traverse ? 1u : 0u; li.flat_leaves = p.flat_k;
     li.partial_bytes = 0;
-    li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
+    li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 160ull;
     if (stats) return collect_stats(h, stream, stats, ev);
     return MI_OK;
   }
@@ -770,7 +777,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.lds_bytes = uint32_t(mi::pt_lds_bytes(p, use_lds_scene(h)));
     li.wide_nodes = p.wide_nodes; li.features = p.features; li.lds_tables = (!use_lds_scene(h) && p.lds_tables) ? 1u : 0u; li.dynamic_fetch = p.dyn_traverse ? 1u : 0u; li.flat_leaves = p.flat_k;
     li.partial_bytes = uint64_t(p.n_chunks) * win.w * win.h * 32ull;
-    li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 96ull;
+    li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 160ull;
   }
   HIP_TRY(hipEventRecord(ev.ev1, stream));
   HIP_TRY(mi::launch_finalize((*ev.partial), rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));

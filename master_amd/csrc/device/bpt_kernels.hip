@@ -39,6 +39,8 @@ struct Ctx {
   f3 sky_horizon, sky_zenith;
   uint32_t n_basic, n_shadow;
   float pre_occ;  // bpt_connect<QN, true>: the visibility stage has walked this connection's shadow ray already (1 = visible)
+  // LDS-resident scenes (QN == 0) with a leaf table: the flat leaf list instead of the tree walk (traverse_flat, pt_device.h; r03).  flat_k = 0: tree.
+  const float* flat_table; uint32_t flat_k, flat_k_mesh;
 };
 
 MI_DEV float betaf(const Ctx& c, float x) {  // Beta.hpp:24-41
@@ -141,6 +143,8 @@ template <int QN>
 MI_DEV Surf scene_intersect(Ctx& c, const Surf& from, f3 dir, uint32_t mask) {
   const f3 org = nudge(from.position, from.gnormal, dir);
   Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+  if (QN == 0 && c.flat_k != 0u) { traverse_flat<false, false, true>(c.sb, (cfloat*)c.flat_table, (c.flat_k + 3u) >> 2, 0xFFFFFFFFu, org, dir, h, nullptr, mask); finish_hit(h); }
+  else
   traverse<false, false, QN, QN == 0 ? 5 : 4>(c.sb, *c.sv, *static_cast<TravStackT<(QN != 0)>*>(c.stack), org, dir, mask, h);  // QN == 0: padded LDS copy of the scene
   ++c.n_basic;
   if (h.id == 0xFFFFFFFFu) { Surf s; s.position = F3(0, 0, 0); s.gnormal = F3(0, 0, 0); s.tangent.c0 = s.tangent.c1 = s.tangent.c2 = F3(0, 0, 0); s.material_id = 0xFFFFFFFFu; return s; }
@@ -149,6 +153,14 @@ MI_DEV Surf scene_intersect(Ctx& c, const Surf& from, f3 dir, uint32_t mask) {
 template <int QN>
 MI_DEV float scene_occluded(Ctx& c, const Surf& origin, const Surf& target) {
   ++c.n_shadow;
+  if (QN == 0 && c.flat_k != 0u) {  // Scene::occluded (Scene.cpp:151-180) through the flat leaf list: occluded() of pt_device.h with traverse_flat
+    const f3 direction = target.position - origin.position;
+    const f3 ao = origin.position + (origin.gnormal * (dot(origin.gnormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+    const f3 at = target.position + (target.gnormal * (dot(target.gnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
+    Hit h; h.t = 1.0f; h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+    traverse_flat<true>(c.sb, (cfloat*)c.flat_table, (c.flat_k_mesh + 3u) >> 2, c.flat_k_mesh >= 32u ? 0xFFFFFFFFu : (1u << c.flat_k_mesh) - 1u, ao, at - ao, h, nullptr);
+    return h.id != 0xFFFFFFFFu ? 0.f : 1.f;
+  }
   return occluded<false, QN, QN == 0 ? 5 : 4>(c.sb, *c.sv, *static_cast<TravStackT<(QN != 0)>*>(c.stack), origin.position, origin.gnormal, target.position, target.gnormal);
 }
 
@@ -461,6 +473,7 @@ MI_DEV Lane lane_decode(const RenderParams& p, const BptState& w, uint32_t i) {
 }
 MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, void* stack, const float4* sb, const SceneView* sv) {
   c.sb = sb; c.sv = sv; c.stack = stack;
+  c.flat_table = p.flat_table; c.flat_k = p.flat_k; c.flat_k_mesh = p.flat_k_mesh;
   c.beta = p.beta; c.roulette = p.roulette; c.rinv = 1.0f / p.roulette;
   c.sphere_c = F3(w.sphere[0], w.sphere[1], w.sphere[2]); c.sphere_r = w.sphere[3];
   c.sky_horizon = F3(w.sky_horizon[0], w.sky_horizon[1], w.sky_horizon[2]); c.sky_zenith = F3(w.sky_zenith[0], w.sky_zenith[1], w.sky_zenith[2]);
@@ -482,7 +495,11 @@ __global__ __launch_bounds__(kBlock, MI_BPT_TRACE_WAVES) void bpt_trace(const Re
   SceneView sv = p.sv;
   const float4* sb = sv.blob;
   uint32_t scene_f4 = 0;
-  if (QN == 0) { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); sb = smem; __syncthreads(); }
+  if (QN == 0) {
+    if (p.flat_k) { scene_f4 = flat_scene_f4(sv, p.flat_k); stage_scene_flat(smem, sv, p.flat_table, p.flat_k, threadIdx.x); }
+    else { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); }
+    sb = smem; __syncthreads();
+  }
   TravStackT<(QN != 0)> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
   stack.cap = p.stack_entries;
@@ -727,7 +744,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const
   SceneView sv = p.sv;
   const float4* sb = sv.blob;
   uint32_t scene_f4 = 0;
-  if (QN == 0) { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); sb = smem; __syncthreads(); }
+  if (QN == 0) { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); sb = smem; __syncthreads(); }  // this stage walks the tree itself: always the tree copy
   TravStackT<(QN != 0)> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
   stack.cap = p.stack_entries;
@@ -865,7 +882,11 @@ __global__ __launch_bounds__(kBlock, PRE ? MI_BPT_ITEMS_PRE_WAVES : MI_BPT_ITEMS
   SceneView sv = p.sv;
   const float4* sb = sv.blob;
   uint32_t scene_f4 = 0;
-  if (QN == 0) { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); sb = smem; __syncthreads(); }
+  if (QN == 0) {
+    if (p.flat_k) { scene_f4 = flat_scene_f4(sv, p.flat_k); stage_scene_flat(smem, sv, p.flat_table, p.flat_k, threadIdx.x); }
+    else { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); }
+    sb = smem; __syncthreads();
+  }
   TravStackT<(QN != 0)> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
   stack.cap = p.stack_entries;
@@ -1006,6 +1027,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_WAVES) void bpt_frame(const RenderPa
   if (ok) {
     Ctx c;
     c.sb = p.sv.blob; c.sv = &p.sv; c.stack = &stack;
+    c.flat_table = nullptr; c.flat_k = 0u; c.flat_k_mesh = 0u;  // the one-kernel form reads the scene from HBM
     c.beta = p.beta; c.roulette = p.roulette; c.rinv = 1.0f / p.roulette;
     c.sphere_c = F3(w.sphere[0], w.sphere[1], w.sphere[2]); c.sphere_r = w.sphere[3];
     c.sky_horizon = F3(w.sky_horizon[0], w.sky_horizon[1], w.sky_horizon[2]); c.sky_zenith = F3(w.sky_zenith[0], w.sky_zenith[1], w.sky_zenith[2]);

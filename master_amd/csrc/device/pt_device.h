@@ -532,8 +532,9 @@ MI_DEV void stage_scene_flat(float4* __restrict__ smem, SceneView& sv, const flo
 }
 
 // one triangle of a leaf record: tri_test with ng read instead of formed (same bits)
-template <bool ANY>
-MI_DEV bool flat_tri(const float4 a, const float4 b, const float4 c, uint32_t idw, uint32_t slot, f3 org, f3 dir, Hit& h) {
+// MASKED (BPT's Scene::intersectMesh): a closest-hit ray that sees only the entities of ray_mask (bit = entity tag)
+template <bool ANY, bool MASKED = false>
+MI_DEV bool flat_tri(const float4 a, const float4 b, const float4 c, uint32_t idw, uint32_t slot, f3 org, f3 dir, Hit& h, uint32_t ray_mask = 0xFFFFFFFFu) {
   const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x), ng = F3(c.y, c.z, c.w);
   const f3 C = v0 - org;
   const f3 R = cross(C, dir);
@@ -544,6 +545,7 @@ MI_DEV bool flat_tri(const float4 a, const float4 b, const float4 c, uint32_t id
   const float V = dot(R, e1) * sgn;
   const float T = dot(ng, C) * sgn;
   if (ANY && (idw >> 30) != uint32_t(MI_ENTITY_MESH)) return false;  // Scene.cpp:42,173: shadow rays see mesh geometry only
+  if (MASKED && !((1u << (idw >> 30)) & ray_mask)) return false;
   if (!(den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absden && absden * 0.0f < T)) return false;
   const float t = T / absden;
   const uint32_t id = idw & 0x3FFFFFFFu;
@@ -566,8 +568,9 @@ MI_DEV bool flat_tri(const float4 a, const float4 b, const float4 c, uint32_t id
 // mask left, so bit k of the mask is entry k.
 // K4: groups of four entries to test (all of them for a closest-hit ray, those holding the mesh leaves for a shadow ray, whose mask is then cut to
 // keep_mask).  h.t = the ray's tfar on entry (closest-hit rays: infinity, the clamp compiles away).
-template <bool ANY, bool COUNT = false>
-MI_DEV void traverse_flat(const float4* __restrict__ leaves, cfloat* __restrict__ table, uint32_t K4, uint32_t keep_mask, f3 org, f3 dir, Hit& h, Visits* vis) {
+template <bool ANY, bool COUNT = false, bool MASKED = false>
+MI_DEV void traverse_flat(const float4* __restrict__ leaves, cfloat* __restrict__ table, uint32_t K4, uint32_t keep_mask, f3 org, f3 dir, Hit& h, Visits* vis,
+                          uint32_t ray_mask = 0xFFFFFFFFu) {
   const RayBox rb = make_raybox(org, dir);
   const f3 ainv = F3(fabsf(rb.inv.x), fabsf(rb.inv.y), fabsf(rb.inv.z));
   uint32_t mask = 0u;
@@ -592,8 +595,8 @@ MI_DEV void traverse_flat(const float4* __restrict__ leaves, cfloat* __restrict_
     const float4 a0 = r[0], a1 = r[1], a2 = r[2], b0 = r[3], b1 = r[4], b2 = r[5];
     const uint2 ids = *reinterpret_cast<const uint2*>(r + 6);
     if (COUNT) vis->tris += 2u;
-    const bool ha = flat_tri<ANY>(a0, a1, a2, ids.x, 2u * k, org, dir, h);
-    const bool hb = flat_tri<ANY>(b0, b1, b2, ids.y, 2u * k + 1u, org, dir, h);
+    const bool ha = flat_tri<ANY, MASKED>(a0, a1, a2, ids.x, 2u * k, org, dir, h, ray_mask);
+    const bool hb = flat_tri<ANY, MASKED>(b0, b1, b2, ids.y, 2u * k + 1u, org, dir, h, ray_mask);
     if (ANY && (ha || hb)) return;
   }
 }

@@ -1206,7 +1206,14 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   if (p.beta == 0.0f && p.features != 15u) p.features &= ~4u;  // FixedBeta<0> needs no pow either (Beta.hpp:24-41)
   p.wide_nodes = h->float_nodes ? 2u : (h->wide_large ? 1u : 0u);  // the BPT kernels walk rays in per-lane loops: wide nodes pay from 100 000 triangles on (profiles/r01/ab_bvh4.txt)
   p.stack_entries = (bpt_staged() && use_lds_scene(h) && h->stack_fits_lds) ? h->info.stack_entries : h->stack_entries_hbm;  // staged kernels stage small scenes into LDS
-  p.flat_k = 0; p.flat_k_mesh = 0;  // the BPT kernels walk the tree
+  {  // staged kernels of LDS-resident scenes: the flat leaf list under the PT rule (8..24 leaf links; MI_PT_FLAT / MI_BPT_FLAT = 0/1 override)
+    const bool lds = bpt_staged() && use_lds_scene(h) && h->stack_fits_lds;
+    bool want = h->flat_k >= kFlatLeavesMin && h->flat_k <= kFlatLeavesDefault;
+    if (const char* e = std::getenv("MI_PT_FLAT")) want = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MI_BPT_FLAT")) want = std::atoi(e) != 0;
+    p.flat_table = h->flat_table;
+    if (lds && want && h->flat_k) { p.flat_k = h->flat_k; p.flat_k_mesh = h->flat_k_mesh; } else { p.flat_k = 0; p.flat_k_mesh = 0; }
+  }
   mi_camera_frame fr;
   rc = mi_camera_setup(&h->scene.cameras[camera_id], float(width) / float(height), &fr);
   if (rc) return rc;

@@ -113,6 +113,27 @@ def test_bpt_one_kernel_form_equals_staged_form(monkeypatch, name):
     np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)
 
 
+@pytest.mark.parametrize("name", ["CornellBoxDiffuse", "CornellBoxPhong", "TestCaseFurnace", "TestCase10", "TestCase12", "MirrorAndAreaLight", "IndirectCubeNone"])
+def test_bpt_flat_leaf_list_is_bit_identical_per_path(monkeypatch, name):
+    """r03: the staged BPT kernels of LDS-resident scenes walk the flat leaf list too (traverse_flat: closest hits under a geometry mask —
+    Scene::intersectMesh — and any-hit shadow rays).  Forced on and off: eye radiance, splat sums, ray and splat counts identical to the tree walk and
+    to the oracle; sun lights, mirrors and tables of 3..29 leaves included."""
+    s = load_scene(name)
+    pt = ma.PathTracing(s, beta=2.0)
+    xy, si = _paths(64, 48, 8000, 11)
+    monkeypatch.setenv("MI_BPT_FLAT", "0")
+    a = pt.bpt_trace_paths(64, 48, xy, si, seed=5)
+    img_a = pt.bpt_render_rgbn(40, 30, spp=6, seed=2)
+    monkeypatch.setenv("MI_BPT_FLAT", "1")
+    b = pt.bpt_trace_paths(64, 48, xy, si, seed=5)
+    img_b = pt.bpt_render_rgbn(40, 30, spp=6, seed=2)
+    assert np.array_equal(a[2], b[2]) and _bits_equal(a[0], b[0]).all() and _bits_equal(a[1], b[1]).all()
+    assert np.array_equal(img_a[..., 3], img_b[..., 3])
+    np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)
+    o = oracle.Oracle(s, beta=2.0).bpt_trace_paths(64, 48, xy, si, seed=5)
+    assert np.array_equal(o[2], b[2]) and _bits_equal(o[0], b[0]).all() and _bits_equal(o[1], b[1]).all()
+
+
 @pytest.mark.parametrize("name,wide", [("CornellBoxDiffuse", 0), ("CornellBoxSpecular", 0), ("CornellBoxSpecular", 1), ("LivingRoomLit", 0), ("LivingRoomLit", 1),
                                        ("MirrorAndAreaLight", 0), ("TestCaseFurnace", 0), ("TestCase10", 1), ("TestCase29", 0)])
 def test_bpt_visibility_stage_is_bit_identical_per_path(monkeypatch, name, wide):

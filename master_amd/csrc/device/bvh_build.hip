@@ -122,6 +122,42 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ data, uint
   for (uint32_t i = b; i < e; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
 }
 
+// Tiled exclusive scan (r03): one workgroup walking a 2 M-entry array in per-thread chunks was serial and uncoalesced (3.9 ms of a 14 ms
+// build).  Tiles of 4096 entries: (1) every tile is scanned in place, coalesced, and leaves its sum; (2) k_scan over the tile sums (one workgroup, at
+// most a few thousand entries); (3) every tile adds its offset.
+constexpr uint32_t kScanTile = 4096u;
+__global__ __launch_bounds__(1024) void k_scan_tile(uint32_t* __restrict__ data, uint32_t total, uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t sums[1024];
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 4u;
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = base + k < total ? data[base + k] : 0u;
+  sums[tid] = v[0] + v[1] + v[2] + v[3];
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t u = tid >= off ? sums[tid - off] : 0u;
+    __syncthreads();
+    sums[tid] += u;
+    __syncthreads();
+  }
+  uint32_t run = tid ? sums[tid - 1] : 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (base + k < total) data[base + k] = run; run += v[k]; }
+  if (tid == 1023u) tile_sums[blockIdx.x] = sums[1023];
+}
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ data, uint32_t total, const uint32_t* __restrict__ tile_offsets) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < total) data[i] += tile_offsets[i / kScanTile];
+}
+// exclusive scan of data[0, total) in place; tile_sums: scratch of at least total / 4096 + 2 entries (unused for short arrays)
+void scan_exclusive(uint32_t* data, uint32_t total, uint32_t* tile_sums, hipStream_t stream) {
+  if (total <= 4u * kScanTile || tile_sums == nullptr) { hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, data, total); return; }
+  const uint32_t tiles = (total + kScanTile - 1u) / kScanTile;
+  hipLaunchKernelGGL(k_scan_tile, dim3(tiles), dim3(1024), 0, stream, data, total, tile_sums);
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, tile_sums, tiles);
+  hipLaunchKernelGGL(k_scan_add, dim3((total + 255u) / 256u), dim3(256), 0, stream, data, total, tile_sums);
+}
+
 __global__ __launch_bounds__(256) void k_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                 uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, uint32_t shift,
                                                 const uint32_t* __restrict__ hist, uint32_t nblk) {
@@ -586,6 +622,8 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
   BUILD_CHECK(scratch.get(reinterpret_cast<void**>(&hist), sizeof(uint32_t) * 256 * size_t(nblk_sort)));
   BUILD_CHECK(scratch.get(reinterpret_cast<void**>(&leaf_parent), sizeof(uint32_t) * size_t(nt)));
   BUILD_CHECK(scratch.get(reinterpret_cast<void**>(&depth), sizeof(uint32_t)));
+  uint32_t* scan_tmp = nullptr;  // tile sums of scan_exclusive: the longest scanned array is max(256 x sort blocks, nt + 1)
+  BUILD_CHECK(scratch.get(reinterpret_cast<void**>(&scan_tmp), sizeof(uint32_t) * ((size_t(nt) + 256u * size_t(nblk_sort)) / kScanTile + 8)));
   const uint32_t ord_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
   BUILD_CHECK(hipMemcpyAsync(scene_ord, ord_init, sizeof ord_init, hipMemcpyHostToDevice, stream));
   BUILD_CHECK(hipMemsetAsync(depth, 0, sizeof(uint32_t), stream));
@@ -603,7 +641,7 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
   uint32_t *vin = vals_a, *vout = vals_b;
   for (uint32_t pass = 0; pass < 8; ++pass) {  // 63-bit codes: 8 passes of 8 bits; ends back in (morton, sorted_tri)
     hipLaunchKernelGGL(k_hist, dim3(nblk_sort), dim3(256), 0, stream, kin, nt, pass * 8, hist, nblk_sort);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, hist, 256u * nblk_sort);
+    scan_exclusive(hist, 256u * nblk_sort, scan_tmp, stream);
     hipLaunchKernelGGL(k_scatter, dim3(nblk_sort), dim3(256), 0, stream, kin, vin, kout, vout, nt, pass * 8, hist, nblk_sort);
     uint64_t* t = kin; kin = kout; kout = t;
     uint32_t* u = vin; vin = vout; vout = u;
@@ -626,7 +664,7 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
       const uint32_t nblk = (n_cur + 255) / 256;
       hipLaunchKernelGGL(k_ploc_nn, dim3(nblk), dim3(256), 0, stream, n_cur, cl_a, nn);
       hipLaunchKernelGGL(k_ploc_count, dim3(nblk), dim3(256), 0, stream, n_cur, nn, counts, nblk);
-      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, counts, 2 * nblk + 1);
+      scan_exclusive(counts, 2 * nblk + 1, scan_tmp, stream);
       hipLaunchKernelGGL(k_ploc_apply, dim3(nblk), dim3(256), 0, stream, n_cur, cl_a, nn, counts, nblk, next_node, cl_b, nodes, leaf_parent);
       uint32_t merged = 0;
       BUILD_CHECK(hipMemcpyAsync(&merged, counts + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -659,7 +697,7 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
       BUILD_CHECK(scratch.get(reinterpret_cast<void**>(&sorted2), sizeof(uint32_t) * size_t(nt)));
       hipLaunchKernelGGL(k_pair_init, dim3((nt + 256) / 256), dim3(256), 0, stream, nt, emits, a_of);
       hipLaunchKernelGGL(k_pair_mark, dim3(gn), dim3(256), 0, stream, n_nodes, plain_links, emits, a_of);
-      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, emits, nt + 1);
+      scan_exclusive(emits, nt + 1, scan_tmp, stream);
       hipLaunchKernelGGL(k_pair_order, dim3(g256), dim3(256), 0, stream, nt, sorted_tri, emits, a_of, perm, sorted2);
       hipLaunchKernelGGL(k_pair_relink, dim3(gn), dim3(256), 0, stream, n_nodes, nodes, plain_links, perm);
       emit_order = sorted2;
@@ -705,11 +743,11 @@ hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qno
                           hipStream_t stream) {
   if (n_nodes == 0) return hipSuccess;
   uint32_t* flag = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&flag), sizeof(uint32_t) * (size_t(n_nodes) + 1));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&flag), sizeof(uint32_t) * (size_t(n_nodes) + 1 + size_t(n_nodes) / kScanTile + 8));
   if (e != hipSuccess) return e;
   hipMemsetAsync(flag + n_nodes, 0, sizeof(uint32_t), stream);
   hipLaunchKernelGGL(k_even_depth, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, flag);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, flag, n_nodes + 1);
+  scan_exclusive(flag, n_nodes + 1, flag + n_nodes + 1, stream);
   hipLaunchKernelGGL(k_collapse4, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, flag, qnodes4, lo[0], lo[1], lo[2], inv_step[0],
                      inv_step[1], inv_step[2]);
   e = hipStreamSynchronize(stream);

@@ -1204,7 +1204,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   if (rc) return rc;
   fill_pt(h, p);
   if (p.beta == 0.0f && p.features != 15u) p.features &= ~4u;  // FixedBeta<0> needs no pow either (Beta.hpp:24-41)
-  p.wide_nodes = h->float_nodes ? 2u : (h->wide_large ? 1u : 0u);  // the BPT kernels walk rays in per-lane loops: wide nodes pay from 100 000 triangles on (profiles/r01/ab_bvh4.txt)
+  p.wide_nodes = h->float_nodes ? 2u : (h->wide_nodes ? 1u : 0u);  // r03: with centre / half-extent children the wide walk is no worse on small scenes and +4 % on LivingRoomLit (r01: from 100 000 triangles on)
   p.stack_entries = (bpt_staged() && use_lds_scene(h) && h->stack_fits_lds) ? h->info.stack_entries : h->stack_entries_hbm;  // staged kernels stage small scenes into LDS
   {  // staged kernels of LDS-resident scenes: the flat leaf list under the PT rule (8..24 leaf links; MI_PT_FLAT / MI_BPT_FLAT = 0/1 override)
     const bool lds = bpt_staged() && use_lds_scene(h) && h->stack_fits_lds;

@@ -536,42 +536,48 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
 
 void mi_pt_destroy(mi_pt_handle* h) {
   if (!h) return;
+  // a failing release must not stay behind as the thread's sticky HIP error (the next mi_pt_create would report it from its own hipGetLastError);
+  // the first one is kept in mi_pt_last_error() for diagnosis
+  bool failed = false;
+#define D(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess && !failed) { failed = true; fail(MI_ERR_INTERNAL, std::string("mi_pt_destroy: " #expr ": ") + hipGetErrorString(e_)); } } while (0)
   (void)hipSetDevice(h->device);
-  if (h->blob) hipFree(h->blob);
-  if (h->qnodes) hipFree(h->qnodes);
-  if (h->qnodes4) hipFree(h->qnodes4);
-  if (h->ce_nodes) hipFree(h->ce_nodes);
-  if (h->plain_links) hipFree(h->plain_links);
-  if (h->flat_table) hipFree(h->flat_table);
-  if (h->d_sorted_tri) hipFree(h->d_sorted_tri);
-  if (h->d_morton) hipFree(h->d_morton);
-  if (h->partial) hipFree(h->partial);
-  if (h->wf_arena) hipFree(h->wf_arena);
-  if (h->bpt_slab) hipFree(h->bpt_slab);
-  if (h->bpt_arena) hipFree(h->bpt_arena);
-  if (h->bpt_values) hipFree(h->bpt_values);
-  if (h->bpt_eye) hipFree(h->bpt_eye);
-  if (h->bpt_light) hipFree(h->bpt_light);
-  if (h->d_rgbn) hipFree(h->d_rgbn);
-  if (h->d_counters) hipFree(h->d_counters);
-  if (h->ev0) hipEventDestroy(h->ev0);
-  if (h->ev1) hipEventDestroy(h->ev1);
-  if (h->h_stage) hipHostFree(h->h_stage);
-  if (h->d_merge) hipFree(h->d_merge);
-  if (h->ev_multi) hipEventDestroy(h->ev_multi);
-  if (h->ev2) hipEventDestroy(h->ev2);
+  if (h->blob) D(hipFree(h->blob));
+  if (h->qnodes) D(hipFree(h->qnodes));
+  if (h->qnodes4) D(hipFree(h->qnodes4));
+  if (h->ce_nodes) D(hipFree(h->ce_nodes));
+  if (h->plain_links) D(hipFree(h->plain_links));
+  if (h->flat_table) D(hipFree(h->flat_table));
+  if (h->d_sorted_tri) D(hipFree(h->d_sorted_tri));
+  if (h->d_morton) D(hipFree(h->d_morton));
+  if (h->partial) D(hipFree(h->partial));
+  if (h->wf_arena) D(hipFree(h->wf_arena));
+  if (h->bpt_slab) D(hipFree(h->bpt_slab));
+  if (h->bpt_arena) D(hipFree(h->bpt_arena));
+  if (h->bpt_values) D(hipFree(h->bpt_values));
+  if (h->bpt_eye) D(hipFree(h->bpt_eye));
+  if (h->bpt_light) D(hipFree(h->bpt_light));
+  if (h->d_rgbn) D(hipFree(h->d_rgbn));
+  if (h->d_counters) D(hipFree(h->d_counters));
+  if (h->ev0) D(hipEventDestroy(h->ev0));
+  if (h->ev1) D(hipEventDestroy(h->ev1));
+  if (h->d_merge) D(hipFree(h->d_merge));
+  if (h->h_stage) D(hipHostFree(h->h_stage));
+  if (h->ev_multi) D(hipEventDestroy(h->ev_multi));
+  if (h->ev2) D(hipEventDestroy(h->ev2));
   for (auto& bs : h->batches) {
     if (bs.pending_mask && bs.ev_copied) (void)hipEventSynchronize(bs.ev_copied);
-    if (bs.d_rgbn) hipFree(bs.d_rgbn);
-    if (bs.h_rgbn) hipHostFree(bs.h_rgbn);
-    if (bs.h_counters) hipHostFree(bs.h_counters);
-    if (bs.partial) hipFree(bs.partial);
-    if (bs.d_counters) hipFree(bs.d_counters);
-    for (hipEvent_t e : {bs.ev0, bs.ev1, bs.ev2, bs.ev_copied}) if (e) hipEventDestroy(e);
-    if (bs.stream) hipStreamDestroy(bs.stream);
+    if (bs.d_rgbn) D(hipFree(bs.d_rgbn));
+    if (bs.h_rgbn) D(hipHostFree(bs.h_rgbn));
+    if (bs.h_counters) D(hipHostFree(bs.h_counters));
+    if (bs.partial) D(hipFree(bs.partial));
+    if (bs.d_counters) D(hipFree(bs.d_counters));
+    for (hipEvent_t e : {bs.ev0, bs.ev1, bs.ev2, bs.ev_copied}) if (e) D(hipEventDestroy(e));
+    if (bs.stream) D(hipStreamDestroy(bs.stream));
   }
-  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->stream) D(hipStreamDestroy(h->stream));
   delete h;
+#undef D
+  (void)hipGetLastError();
 }
 
 int mi_pt_set_kernel(mi_pt_handle* h, int kernel) {
@@ -976,8 +982,6 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
     if (rc == MI_OK) rc = ensure(reinterpret_cast<void**>(&h->d_rgbn), &h->rgbn_bytes, bytes);
     if (rc == MI_OK && !device_merge && h->h_stage_bytes < bytes) {
       if (h->h_stage) hipHostFree(h->h_stage);
-  if (h->d_merge) hipFree(h->d_merge);
-  if (h->ev_multi) hipEventDestroy(h->ev_multi);
       h->h_stage = nullptr; h->h_stage_bytes = 0;
       if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), bytes, hipHostMallocDefault) != hipSuccess) rc = fail(MI_ERR_OUT_OF_MEMORY, "pinned host staging buffer");
       else h->h_stage_bytes = bytes;

@@ -447,6 +447,20 @@ def test_one_process_multi_device_render_is_bit_identical(cornell, kernel, merge
             assert (st.num_paths, st.num_basic_rays, st.num_shadow_rays, st.numeric_errors) == (rs.num_paths, rs.num_basic_rays, rs.num_shadow_rays, rs.numeric_errors)
             assert kernel == ma.KERNEL_WAVEFRONT or st.gpu_ms > 0
             assert ma.lib().mi_pt_last_multi_merge() == (1 if merge == "device" else 0)
+    # both merges on the SAME handles, back and forth (r03: the host path once released the device path's frame and event — a double free at destroy
+    # whose error the next mi_pt_create reported as its own), then destroy and create again
+    if merge == "device":
+        ref2 = pts[0].render_rgbn(96, 64, spp=2, seed=5)
+        for host in ("1", "0", "1", "0"):
+            monkeypatch.setenv("MI_PT_MULTI_HOST_MERGE", host)
+            img, _ = ma.render_multi(pts, 96, 64, spp=2, seed=5)
+            assert np.array_equal(img.view(np.uint32), ref2.view(np.uint32)) and ma.lib().mi_pt_last_multi_merge() == (0 if host == "1" else 1)
+        monkeypatch.delenv("MI_PT_MULTI_HOST_MERGE")
+        spare = [ma.PathTracing(cornell, max_path=8) for _ in range(2)]
+        ma.render_multi(spare, 64, 64, spp=1, seed=1)
+        del spare
+        again = ma.PathTracing(cornell, max_path=8)   # a release that failed would surface here
+        assert np.array_equal(again.render_rgbn(24, 24, spp=2, seed=11, sample_offset=3), pts[0].render_rgbn(24, 24, spp=2, seed=11, sample_offset=3))
     own = pts[1].render_rgbn(64, 64, spp=1, seed=1)   # still sharded (1 of 2): the left 32 columns of the upper tile row... belong to rank 0
     assert (own[:32, :32, 3] == 0).all() and (own[:32, 32:, 3] == 1).all()
     with pytest.raises(ma.MiError):

@@ -325,18 +325,7 @@ static void lab_flat_ray(const orc_scene* s, v3 org, v3 dir, uint32_t ray_mask, 
   hit_t h; h.t = tmax; h.u = h.v = 0; h.id = UINT32_MAX; h.tri = 0;
   /* pass 1: nearest box first */
   float best_tn = INFINITY; int best = -1;
-  int entered_plane = 0;
-  for (int i = 0; i < g_nflat; ++i) { float tn; if (box_test(g_flat[i].lo, g_flat[i].hi, org, inv, tmax, &tn)) { ++entered; if (tn < best_tn) { best_tn = tn; best = i; }
-    /* plane refinement: the leaf's quad is planar — does the ray cross its plane inside the box's [tn, tf]? */
-    { const tri_t* tr = &s->tris_sorted[g_flat[i].a];
-      float t0x = (g_flat[i].lo[0] - org.x) * inv.x, t1x = (g_flat[i].hi[0] - org.x) * inv.x, t0y = (g_flat[i].lo[1] - org.y) * inv.y, t1y = (g_flat[i].hi[1] - org.y) * inv.y;
-      float t0z = (g_flat[i].lo[2] - org.z) * inv.z, t1z = (g_flat[i].hi[2] - org.z) * inv.z;
-      float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
-      float den = vdot(tr->ng, dir), num = vdot(tr->ng, vsub(tr->v0, org));
-      float tp = num / den;
-      int coplanar_pair = 1;
-      if (g_flat[i].b >= 0) { const tri_t* tb = &s->tris_sorted[g_flat[i].b]; v3 c = vcross(tr->ng, tb->ng); coplanar_pair = (fabsf(c.x) + fabsf(c.y) + fabsf(c.z)) < 1e-6f * (fabsf(tr->ng.x)+fabsf(tr->ng.y)+fabsf(tr->ng.z)) * (fabsf(tb->ng.x)+fabsf(tb->ng.y)+fabsf(tb->ng.z)); }
-      if (!coplanar_pair || den == 0.0f || (tp >= tn - 1e-4f * (1.0f + fabsf(tn)) && tp <= tf + 1e-4f * (1.0f + fabsf(tf)))) ++entered_plane; } } }
+  for (int i = 0; i < g_nflat; ++i) { float tn; if (box_test(g_flat[i].lo, g_flat[i].hi, org, inv, tmax, &tn)) { ++entered; if (tn < best_tn) { best_tn = tn; best = i; } } }
   if (closest && best >= 0) {
     tri_test(&s->tris_sorted[g_flat[best].a], org, dir, ray_mask, 0.0f, &h, 1);
     if (g_flat[best].b >= 0) tri_test(&s->tris_sorted[g_flat[best].b], org, dir, ray_mask, 0.0f, &h, 1);
@@ -349,7 +338,6 @@ static void lab_flat_ray(const orc_scene* s, v3 org, v3 dir, uint32_t ray_mask, 
       else if (g_flat[i].b >= 0 && tri_test(&s->tris_sorted[g_flat[i].b], org, dir, ray_mask, 0.0f, &h, 0)) done = 1;
     } }
   }
-  if (closest) entered2 = entered_plane;  /* experiment: report the plane-refined count in this field */
   g_flat_log[g_flat_n++] = (uint32_t)closest | ((uint32_t)entered << 4) | ((uint32_t)tested << 12) | ((uint32_t)entered2 << 20) | ((uint32_t)done << 28);
 }
 

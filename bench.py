@@ -129,10 +129,113 @@ def cpu_baseline(scene, args, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or spp_done >= args.spp:
             break
-    return {"value": segs / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(), "build": flags,
-            "embree_on_host": embree_on_host(),
+    # BASELINE configs[0] (C1) exactly: CornellBoxDiffuse 256x256, 64 spp, max path 4, the whole job, median of 3 (SURVEY 8(d) "CPU baseline timing")
+    c1 = None
+    if args.scene == "CornellBoxDiffuse":
+        o1 = oracle.Oracle(scene, lights=1.0, roulette=0.9, beta=1.0, max_path=4)
+        runs = []
+        for k in range(3):
+            t1 = time.perf_counter()
+            o1.render_rgbn(256, 256, spp=64, seed=1 + k, threads=threads)
+            runs.append((time.perf_counter() - t1, o1.last_stats.num_basic_rays))
+        runs.sort()
+        c1 = {"workload": "CornellBoxDiffuse, PT, 256x256, 64 spp, max path 4 (BASELINE configs[0])", "seconds_median_of_3": runs[1][0], "seconds_all": [r[0] for r in runs],
+              "value": runs[1][1] / runs[1][0] / 1e6, "unit": "Msamples/s", "cores": threads}
+    return {"value": segs / dt / 1e6, "unit": "Msamples/s", "cores": threads, "cores_online": os.cpu_count(), "kind": "port", "cpu_model": cpu_model(), "build": flags,
+            "embree_on_host": embree_on_host(), "c1": c1,
             "sample": "%s %dx%d max_path %s, %d spp of %d, %.1f s, CPU restatement of reference PT (own BVH, non-Embree), pthreads over 32x32 tiles" % (
                 args.scene, args.width, args.height, args.max_path, spp_done, args.spp, dt)}
+
+
+
+# ---- hardware counters of the launches this run times, measured in this run ----
+# Counters need their own passes (MI355X_MICROARCH.md, rocprofv3 PMC slots: FETCH_SIZE and WRITE_SIZE do not fit one pass; never next to tracing domains), and
+# a process that has touched the GPU must not be profiled after the fact: so BEFORE this process initialises HIP it starts, one after the other, three fresh
+# child processes `rocprofv3 --pmc <set> -- <python3> tools/one_launch.py <workloads>` (interpreter binary directly after `--`), each launching every
+# workload of the line once.  FETCH_SIZE is doubled (the guide's gfx950 correction: 128-byte requests tallied at 64 B), WRITE_SIZE is exact.
+PMC_PASSES = (
+    ("valu", "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAVES GRBM_GUI_ACTIVE"),
+    ("fetch", "FETCH_SIZE"),
+    ("write", "WRITE_SIZE"),
+)
+
+
+def pmc_spec(scene, W, H, spp, max_path, shard=None):
+    return "%s:%dx%dx%d:%d%s" % (scene, W, H, spp, 0 if max_path >= (1 << 62) else max_path, ":%d/%d" % shard if shard else "")
+
+
+def collect_live_pmc(specs, timeout_s=300.0, keep_dir=None):
+    """{spec: counters} for the megakernel launch of every workload, or ({}, reason) when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {}, "rocprofv3 not found"
+    py = os.path.realpath(sys.executable)
+    base = keep_dir or tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+    os.makedirs(base, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    per_launch = [dict() for _ in specs]
+    t0 = time.perf_counter()
+    for name, counters in PMC_PASSES:
+        d = os.path.join(base, name)
+        lj = os.path.join(base, name + "_launches.json")
+        cmd = [rocprof, "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "--", py, os.path.join(ROOT, "tools", "one_launch.py"), lj] + list(specs)
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+        except Exception as e:  # noqa: BLE001
+            return {}, "pass %s: %r" % (name, e)
+        if r.returncode != 0 or not os.path.exists(lj):
+            return {}, "pass %s failed (rc %d): %s" % (name, r.returncode, r.stdout.decode(errors="replace")[-300:])
+        rows = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "pt_megakernel" in row["Kernel_Name"]:
+                    acc = rows.setdefault(int(row["Dispatch_Id"]), {"kernel": row["Kernel_Name"].split("(")[0]})
+                    acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        order = sorted(rows)
+        if len(order) != len(specs):
+            return {}, "pass %s: %d megakernel dispatches for %d workloads" % (name, len(order), len(specs))
+        launches = json.load(open(lj))["launches"]
+        for i, did in enumerate(order):
+            per_launch[i].update(rows[did])
+            per_launch[i].setdefault("segments", launches[i]["segments"])
+    out = {}
+    for spec, c in zip(specs, per_launch):
+        e = {"pmc_live": True, "source": "live: rocprofv3 --pmc child processes of this bench run (tools/one_launch.py), one launch per pass", "kernel": c.get("kernel"),
+             "segments_per_launch": c.get("segments")}
+        if "FETCH_SIZE" in c:
+            e["fetch_bytes"] = c["FETCH_SIZE"] * 1024 * 2
+        if "WRITE_SIZE" in c:
+            e["write_bytes"] = c["WRITE_SIZE"] * 1024
+        if "fetch_bytes" in e and "write_bytes" in e:
+            e["hbm_bytes_per_launch"] = e["fetch_bytes"] + e["write_bytes"]
+        cyc = c.get("GRBM_GUI_ACTIVE")
+        if cyc and "SQ_ACTIVE_INST_VALU" in c:
+            e["kernel_cycles_per_xcd"] = cyc / 8
+            e["valu_issue_utilisation"] = c["SQ_ACTIVE_INST_VALU"] * 2 / (cyc / 8 * 1024)
+            e["valu_thread_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64)
+        if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c:
+            e["wait_any_frac_of_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"):
+            if k in c:
+                e[k] = c[k]
+        if c.get("segments") and "SQ_INSTS_VALU" in c:
+            e["valu_instructions_per_segment_lane"] = c["SQ_INSTS_VALU"] * 64.0 / c["segments"]  # wave instructions x 64 lanes / segments: 64 = every lane busy
+        out[spec] = e
+    out["_seconds"] = time.perf_counter() - t0
+    if not keep_dir:
+        shutil.rmtree(base, ignore_errors=True)
+    return out, None
+
+
+def under_profiler():
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH")) or \
+        any(k.startswith("ROCPROF") for k in os.environ)
 
 
 def load_scene(name):
@@ -156,8 +259,17 @@ def traffic_entry(key):
     return None
 
 
-def roofline_block(ma, pt, ist, seg_per_launch, avg_ms, li, key):
-    """The dominant kernel's roofline for one workload.  ist: statistics of the instrumented variant on the same workload."""
+def roofline_block(ma, pt, ist, seg_per_launch, avg_ms, li, key, live=None):
+    """The dominant kernel's roofline for one workload.  ist: statistics of the instrumented variant on the same workload; live: the counters of
+    this workload's launch measured by this run's rocprofv3 child processes (collect_live_pmc), else the builder's recorded passes (profiles/traffic.json)
+    with "pmc_live": false.
+
+    What bounds the kernel decides what `frac` is:
+      * LDS-resident scene (C2): SURVEY 8(d)'s per-segment bytes are LDS / scalar-cache reads there, HBM sees the FP64 partial sums only.  The kernel is
+        VALU-issue bound: bound "valu", frac = issue x lanes of the FP32 lane-issue slots, achieved = frac x 157.3 TFLOP/s; the HBM figures sit under `hbm`.
+      * scene read from HBM / Infinity Cache: bound "hbm", frac = the fabric traffic the counters MEASURED / launch time / 8 TB/s; the algorithmic
+        figure (8(d) bytes, cache-served bytes included) is kept beside it as `algorithmic_frac_cache_served`.  Without counters: the algorithmic figure,
+        capped by what it can mean, labelled as such."""
     kernel = pt.get_kernel()
     lds_scene = kernel == ma.KERNEL_MEGA_LDS
     node_bytes = 64.0  # SURVEY 8(d) prices a visited node at 64 B whatever the build stores (32-byte quantised nodes read half of that)
@@ -165,45 +277,52 @@ def roofline_block(ma, pt, ist, seg_per_launch, avg_ms, li, key):
         node_bytes = 32.0  # flat leaf list: N counts the leaf-table entries a ray is tested against (32 B each, scalar loads), T two triangles per leaf entered
     b_sample, terms = algorithmic_bytes_per_sample(ist, wavefront=kernel == ma.KERNEL_WAVEFRONT, node_bytes=node_bytes)
     launch_s = avg_ms * 1e-3
-    pmc = traffic_entry(key)
+    pmc = live if live else traffic_entry(key)
+    if pmc is not None and not live:
+        pmc = dict(pmc, pmc_live=False)
     traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
     algorithmic_gbs = b_sample * seg_per_launch / launch_s / 1e9
-    # compulsory HBM bytes of a launch of the LDS-resident kernel: the FP64 partial sums (written once, read once by pt_finalize)
-    compulsory = float(li.partial_bytes)
-    rl = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "pt_megakernel", "avg_launch_ms": avg_ms,
-          "algorithmic_bytes_per_sample": b_sample, "terms": terms, "traffic": traffic, "pmc": pmc}
-    if kernel == ma.KERNEL_WAVEFRONT:
-        rl["kernel"] = "wavefront pipeline (all kernels of one step)"
-    if lds_scene or algorithmic_gbs > HBM_PEAK_GBS:
-        # the scene bytes never reach HBM: price the kernel's HBM side by what was measured (or, without a PMC record, by the
-        # bytes it must write), and report the algorithmic figure as what it is — bytes served by LDS / caches
-        hbm_bytes = traffic if traffic is not None else compulsory
-        rl["achieved"] = hbm_bytes / launch_s / 1e9
-        rl["achieved_source"] = "measured HBM bytes per launch (rocprofv3 PMC, %s)" % pmc["source"] if traffic is not None else \
-            "compulsory HBM bytes of the launch (FP64 partial sums); no PMC record for this workload"
-        rl["scene_bytes_served_by"] = "LDS" if lds_scene else "L2 / Infinity Cache"
-        rl["algorithmic_GBs_not_hbm"] = algorithmic_gbs
-        rl["note"] = ("the scene is LDS-resident: SURVEY 8(d)'s per-segment bytes are LDS reads, so the HBM fraction is tiny by design and the bound "
-                      "that matters is `valu`" if lds_scene else "the scene is cache-resident: algorithmic bytes exceed what HBM could deliver")
-    else:
-        rl["achieved"] = algorithmic_gbs
-        rl["achieved_source"] = "SURVEY 8(d) algorithmic bytes per segment x segments per launch / launch time (HIP events)"
-        rl["note"] = "bytes served by L2 / Infinity Cache count towards `achieved`; `traffic` is what the PMC counters saw leave the L2"
-    rl["frac"] = rl["achieved"] / HBM_PEAK_GBS
-    assert rl["frac"] <= 1.0, "roofline.frac must be a fraction"
-    if traffic is not None:  # what the PMC counters saw leave the L2, against the HBM peak (VERDICT r02 #4c): the algorithmic figure counts cache-served bytes too
-        rl["hbm_measured_frac"] = traffic / launch_s / 1e9 / HBM_PEAK_GBS
-    if li.flat_leaves:
-        rl["traversal"] = "flat leaf list: %d leaf boxes per ray in one wave-uniform loop (scalar operands), then per-lane tests of the leaves entered" % li.flat_leaves
-    # VALU view: issue utilisation and active lanes per issued instruction need PMC counters (separate rocprofv3 passes); the
-    # traversal loops' lane efficiency is measured in this run by the instrumented kernel
+    compulsory = float(li.partial_bytes)  # the FP64 partial sums (written once, read once by pt_finalize)
+    hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_sample": b_sample, "algorithmic_GBs": algorithmic_gbs, "traffic_bytes_per_launch": traffic}
+    if traffic is not None:
+        hbm["measured_GBs"] = traffic / launch_s / 1e9
+        hbm["hbm_measured_frac"] = hbm["measured_GBs"] / HBM_PEAK_GBS
     valu = {"traversal_lane_efficiency_in_run": {"closest": terms["simd_efficiency_closest_traversal"], "shadow": terms["simd_efficiency_shadow_traversal"]},
             "peak_TFLOPs_fp32": FP32_PEAK_TFLOPS}
     if pmc and "valu_issue_utilisation" in pmc:
         valu.update(issue=pmc["valu_issue_utilisation"], lanes=pmc["valu_thread_utilisation"],
-                    frac=pmc["valu_issue_utilisation"] * pmc["valu_thread_utilisation"], source=pmc["source"],
+                    frac=pmc["valu_issue_utilisation"] * pmc["valu_thread_utilisation"],
                     note="issue = SQ_ACTIVE_INST_VALU x 2 cycles / (kernel cycles x 1024 SIMDs); lanes = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
                          "frac = fraction of the FP32 lane-issue slots of the chip doing path work")
+        if pmc.get("valu_instructions_per_segment_lane"):
+            valu["instructions_per_segment_lane"] = pmc["valu_instructions_per_segment_lane"]
+    rl = {"kernel": (pmc.get("kernel") if pmc else None) or "pt_megakernel", "avg_launch_ms": avg_ms, "traffic": traffic, "pmc_live": bool(pmc and pmc.get("pmc_live")),
+          "pmc": pmc, "terms": terms, "algorithmic_bytes_per_sample": b_sample}
+    if kernel == ma.KERNEL_WAVEFRONT:
+        rl["kernel"] = "wavefront pipeline (all kernels of one step)"
+    if lds_scene:
+        hbm["scene_bytes_served_by"] = "LDS"
+        hbm["compulsory_bytes_per_launch"] = compulsory
+        if "frac" in valu:
+            rl.update(bound="valu", peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", achieved=valu["frac"] * FP32_PEAK_TFLOPS, frac=valu["frac"],
+                      note="LDS-resident scene: instruction-issue bound.  frac = VALU issue utilisation x active lanes per issued instruction = the share of the chip's FP32 "
+                           "lane-issue slots doing path work; achieved = frac x peak (fma-equivalent).  SURVEY 8(d)'s bytes are LDS / scalar-cache reads here (`hbm`).")
+        else:  # no counters at all: the only measured thing is the HBM side
+            rl.update(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", achieved=compulsory / launch_s / 1e9, frac=compulsory / launch_s / 1e9 / HBM_PEAK_GBS,
+                      note="no PMC counters available: compulsory HBM bytes of the launch (FP64 partial sums) only; the kernel is VALU-bound")
+    else:
+        rl.update(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s")
+        if traffic is not None:
+            rl.update(achieved=hbm["measured_GBs"], frac=hbm["hbm_measured_frac"], algorithmic_frac_cache_served=algorithmic_gbs / HBM_PEAK_GBS,
+                      note="frac = fabric traffic MEASURED by the counters (FETCH_SIZE x 2 + WRITE_SIZE) / launch time / 8 TB/s; `algorithmic_frac_cache_served` prices "
+                           "SURVEY 8(d)'s bytes per segment, which L2 and the Infinity Cache serve in part (it may exceed 1)")
+        else:
+            rl.update(achieved=min(algorithmic_gbs, HBM_PEAK_GBS), frac=min(algorithmic_gbs / HBM_PEAK_GBS, 1.0), algorithmic_frac_cache_served=algorithmic_gbs / HBM_PEAK_GBS,
+                      note="no PMC counters: SURVEY 8(d) algorithmic bytes per segment x segments / launch time, cache-served bytes included")
+    assert rl["frac"] <= 1.0, "roofline.frac must be a fraction"
+    if li.flat_leaves:
+        rl["traversal"] = "flat leaf list: %d leaf boxes per ray in one wave-uniform loop (scalar operands), then per-lane tests of the leaves entered" % li.flat_leaves
+    rl["hbm"] = hbm
     rl["valu"] = valu
     return rl
 
@@ -233,7 +352,30 @@ def main():
     ap.add_argument("--hbm-size2", default="1920x1080x64")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses N ranks on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="map every rank onto the visible GPUs modulo their count (rehearsal only)")
+    ap.add_argument("--c5-scene", default="clutter", help="BASELINE configs[4] stand-in for the one-rank share block ('' skips it)")
+    ap.add_argument("--c5-size", default="3840x2160x4096", help="WxHxSPP of configs[4]; the block renders rank 0's tiles of world 8 at ALL samples = the 512-spp-per-GPU unit")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not start the rocprofv3 --pmc child processes (roofline then replays profiles/traffic.json, pmc_live false)")
+    ap.add_argument("--pmc-dir", default="", help="keep the counter CSVs of the live PMC passes here (e.g. gpurun_out/pmc_live)")
     args = ap.parse_args()
+    if args.max_path <= 0:
+        args.max_path = (1 << 63) - 1
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    plain_run = world_env == 1 and not args.kernel
+
+    # hardware counters of the launches this line times: fresh child processes, BEFORE this process touches the GPU
+    live_pmc, live_pmc_error = {}, "not requested"
+    hbm_sizes = [(args.hbm_scene, args.hbm_size, None), (args.hbm_scene2, args.hbm_size2, None), (args.c5_scene, args.c5_size, (0, 8))]
+    if world_env == 1 and not args.no_live_pmc and plain_run:
+        if under_profiler():
+            live_pmc_error = "this process runs under a profiler itself"
+        else:
+            specs = [pmc_spec(args.scene, args.width, args.height, args.spp, args.max_path)]
+            if not args.no_hbm_workload:
+                for sc, size, shard in hbm_sizes:
+                    if sc:
+                        w_, h_, s_ = [int(x) for x in size.split("x")]
+                        specs.append(pmc_spec(sc, w_, h_, s_, (1 << 63) - 1, shard))
+            live_pmc, live_pmc_error = collect_live_pmc(specs, keep_dir=args.pmc_dir or None)
 
     import torch
     import torch.distributed as dist
@@ -262,8 +404,6 @@ def main():
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     scene = load_scene(args.scene)
-    if args.max_path <= 0:
-        args.max_path = ma.PTRDIFF_MAX
     pt = ma.PathTracing(scene, lights=1.0, roulette=0.9, beta=1.0, max_path=args.max_path, device=local_rank)
     if args.kernel:
         pt.set_kernel(args.kernel)
@@ -357,7 +497,12 @@ def main():
         ist = pt.render_device(fb.data_ptr(), W, H, spp=min(args.spp, 64), seed=seed, sample_offset=0, stream=stream, want_stats=True)
         pt.set_instrumented(False)
         avg_ms = sum(kernel_ms) / len(kernel_ms)
-        rl = roofline_block(ma, pt, ist, float(st.num_basic_rays), avg_ms, li, workload_key(args.scene, W, H, args.spp, args.max_path))
+        rl = roofline_block(ma, pt, ist, float(st.num_basic_rays), avg_ms, li, workload_key(args.scene, W, H, args.spp, args.max_path),
+                            live=live_pmc.get(pmc_spec(args.scene, W, H, args.spp, args.max_path)))
+        if not rl["pmc_live"]:
+            rl["pmc_live_error"] = live_pmc_error
+        elif "_seconds" in live_pmc:
+            rl["pmc_live_seconds"] = live_pmc["_seconds"]
         is_c2 = (args.scene, W, H, args.spp, args.max_path) == ("CornellBoxDiffuse", 512, 512, 1024, 8)
         procedural = args.scene.split(":")[0] in ("atrium", "clutter")
         out = {
@@ -385,9 +530,12 @@ def main():
             out["per_rank"] = per_rank
     del pt
     if rank == 0 and world == 1 and not args.no_hbm_workload:
-        out["hbm_workload"] = hbm_workload(ma, torch, args, seed, args.hbm_scene, args.hbm_size)
+        out["hbm_workload"] = hbm_workload(ma, torch, args, seed, args.hbm_scene, args.hbm_size, live_pmc=live_pmc)
         if args.hbm_scene2:  # a scene beyond the 256 MB Infinity Cache: the kernel that really reaches HBM
-            out["hbm_workload_beyond_cache"] = hbm_workload(ma, torch, args, seed, args.hbm_scene2, args.hbm_size2)
+            out["hbm_workload_beyond_cache"] = hbm_workload(ma, torch, args, seed, args.hbm_scene2, args.hbm_size2, live_pmc=live_pmc)
+        if args.c5_scene:  # BASELINE configs[4]: what ONE of its eight GPUs renders — rank 0's 32x32 tiles of the 3840x2160 frame, all 4096 samples of them
+            out["c5_rank_share"] = hbm_workload(ma, torch, args, seed, args.c5_scene, args.c5_size, live_pmc=live_pmc, shard=(0, 8), steps=1,
+                                                stands_for="BASELINE configs[4] BreakfastRoom1, one rank's share of the 8-GPU pixel-tile shard")
     if rank == 0 and world == 1 and not args.no_time_to_rmse and args.scene == "CornellBoxDiffuse":
         try:  # the second half of BASELINE.json's metric; never allowed to cost the line
             out["time_to_rmse"] = time_to_rmse(ma, scene, args)
@@ -432,21 +580,23 @@ def time_to_rmse(ma, scene, args, target=0.01, frame_spp=16, ref_spp=65536, max_
             "includes": "per-call framebuffer download and host-side RMS (ImageView.cpp:60-85)"}
 
 
-def hbm_workload(ma, torch, args, seed, scene_name, size):
-    """One HBM-resident configuration after the primary timed region: 1 warm-up + 2 steps, own ms_per_step and roofline."""
+def hbm_workload(ma, torch, args, seed, scene_name, size, live_pmc=None, shard=None, steps=2, stands_for="BASELINE configs[3] CrytekSponza"):
+    """One configuration whose scene is read from HBM, after the primary timed region: 1 warm-up + `steps` steps, own ms_per_step and roofline.
+    shard = (rank, world): that rank's 32x32 tiles of the frame (mi_pt_set_tile_shard, Technique.cpp:167), all `spp` samples of them."""
     W, H, spp = [int(x) for x in size.split("x")]
     t0 = time.perf_counter()
     scene = load_scene(scene_name)
     t_scene = time.perf_counter() - t0
     pt = ma.PathTracing(scene, lights=1.0, roulette=0.9, beta=1.0, max_path=ma.PTRDIFF_MAX, device=torch.cuda.current_device())
+    if shard:
+        pt.set_tile_shard(*shard)
     fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    pt.render_device(fb.data_ptr(), W, H, spp=spp, seed=seed, sample_offset=0, stream=stream, want_stats=True)  # warm-up
+    pt.render_device(fb.data_ptr(), W, H, spp=min(spp, 256), seed=seed, sample_offset=0, stream=stream, want_stats=True)  # warm-up: code, scene and partial buffers paged in
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     segs = shadow = paths = 0
     kernel_ms = []
-    steps = 2
     for i in range(steps):
         st = pt.render_device(fb.data_ptr(), W, H, spp=spp, seed=seed, sample_offset=(1 + i) * spp, stream=stream, want_stats=True)
         segs += st.num_basic_rays; shadow += st.num_shadow_rays; paths += st.num_paths
@@ -454,21 +604,40 @@ def hbm_workload(ma, torch, args, seed, scene_name, size):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     li = pt.last_launch()
-    denom_ok = bool((fb[..., 3] == float(spp)).all().item())  # of the last timed step: the instrumented pass below renders into fb again
+    den = fb[..., 3]
+    owned = den > 0 if shard else torch.ones_like(den, dtype=torch.bool)
+    # of the last timed step (the instrumented pass below renders into fb again).  Glass without a TIR guard drops samples (BSDF.cpp:480-493): the sum is what must add up
+    denom_ok = bool((den[owned] == float(spp)).all().item())
+    denom_missing = int(owned.sum().item()) * spp - int(den.double().sum().item())
     pt.set_instrumented(True)
     ist = pt.render_device(fb.data_ptr(), W, H, spp=min(spp, 8), seed=seed, sample_offset=0, stream=stream, want_stats=True)
     pt.set_instrumented(False)
     info = pt.bvh_info()
     avg_ms = sum(kernel_ms) / len(kernel_ms)
-    rl = roofline_block(ma, pt, ist, float(st.num_basic_rays), avg_ms, li, workload_key(scene_name, W, H, spp, 999))
-    return {"workload": "%s (procedural stand-in for BASELINE configs[3] CrytekSponza: %d triangles, BVH depth %d), PT, %dx%d, %d spp, unbounded paths, beta 1, roulette 0.9" % (
-                scene_name, info.n_triangles, info.max_depth, W, H, spp),
-            "value": segs / elapsed / 1e6, "unit": "Msamples/s", "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3,
-            "Mpaths_per_s": paths / elapsed / 1e6, "Mrays_per_s": (segs + shadow) / elapsed / 1e6,
-            "scene_bytes_in_hbm": li.scene_bytes, "node_records": {0: "32-byte quantised binary", 1: "64-byte quantised wide (4 grandchildren)", 2: "64-byte float binary"}[li.wide_nodes],
-            "tables_in_lds": bool(li.lds_tables), "dynamic_fetch_traversal": bool(li.dynamic_fetch), "scene_build_s": t_scene, "bvh_build_ms": info.build_ms,
-            "denom_equals_spp": denom_ok,
-            "roofline": rl}
+    live = (live_pmc or {}).get(pmc_spec(scene_name, W, H, spp, ma.PTRDIFF_MAX, shard))
+    rl = roofline_block(ma, pt, ist, float(st.num_basic_rays), avg_ms, li, workload_key(scene_name, W, H, spp, 999), live=live)
+    out = {"workload": "%s (procedural stand-in for %s: %d triangles, BVH depth %d), PT, %dx%d, %d spp%s, unbounded paths, beta 1, roulette 0.9" % (
+               scene_name, stands_for, info.n_triangles, info.max_depth, W, H, spp,
+               " of the 32x32 tiles {t : t mod %d == %d} (%d pixels)" % (shard[1], shard[0], int(owned.sum().item())) if shard else ""),
+           "value": segs / elapsed / 1e6, "unit": "Msamples/s", "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3,
+           "Mpaths_per_s": paths / elapsed / 1e6, "Mrays_per_s": (segs + shadow) / elapsed / 1e6,
+           "scene_bytes_in_hbm": li.scene_bytes, "node_records": {0: "32-byte quantised binary", 1: "64-byte quantised wide (4 grandchildren)", 2: "64-byte float binary"}[li.wide_nodes],
+           "tables_in_lds": bool(li.lds_tables), "dynamic_fetch_traversal": bool(li.dynamic_fetch), "scene_build_s": t_scene, "bvh_build_ms": info.build_ms,
+           "denom_equals_spp": denom_ok, "denominators_missing": denom_missing,
+           "denominators_missing_equals_numeric_errors": (denom_missing == int(st.numeric_errors)) if steps == 1 else None,
+           "roofline": rl}
+    if shard:
+        # what the 8-GPU job adds to this share: ONE all-reduce(sum) of the [H][W][4] f32 framebuffer (merge_exr, Options.cpp:1340-1409).  Not executed here (one GPU
+        # per box); bounded on paper: a ring all-reduce moves 2 (N-1)/N of the buffer over each GPU's links, xGMI gives 7 links x ~153 GB/s per GPU, a ring uses one
+        # per direction (MI355X_MICROARCH.md chip-level parameters) — so >= this many ms even on ONE link, against the seconds of the share
+        rb = W * H * 16
+        ring_ms_one_link = 2.0 * (shard[1] - 1) / shard[1] * rb / 153e9 * 1e3
+        share_ms = elapsed / steps * 1e3
+        out["reduce_bytes"] = rb
+        out["reduce"] = {"bytes": rb, "MiB": rb / 2.0 ** 20, "executed": False, "ring_allreduce_ms_on_one_xgmi_link": ring_ms_one_link,
+                         "weak_scaling_efficiency_bound": share_ms / (share_ms + ring_ms_one_link),
+                         "note": "8-GPU efficiency bounded on paper as T(share) / (T(share) + reduce); no RCCL call across GPUs has run (one GPU per box)"}
+    return out
 
 
 if __name__ == "__main__":

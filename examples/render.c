@@ -2,7 +2,8 @@
  * does in the reference (main.cpp -> Application -> Technique::render -> save_exr, exr.cpp:177-232), without its frame loop.
  *
  *   cc -std=c11 -I include examples/render.c -o render master_amd/libmi_pt.so -Wl,-rpath,$PWD/master_amd
- *   ./render scenes/CornellBoxDiffuse.miscene out.exr [--BPT] [--spp 64] [--size 512x512] [--max-path 8] [--beta 1] [--roulette 0.9] [--gpus N]
+ *   ./render scenes/CornellBoxDiffuse.miscene out.exr [--BPT] [--spp 64] [--size 512x512] [--max-path 8] [--beta 1] [--roulette 0.9] [--gpus N] [--lamp-scale 0.01]
+ * --lamp-scale S: mi_blend_options.lamp_energy_scale of the .blend reader (1 = stock assimp units, 0.01 = the constant of unit_test.py:77-83).
  * --gpus N renders PT on N devices of this one process (mi_pt_render_multi); with fewer devices than N they are shared.
  */
 #include <stdio.h>
@@ -17,9 +18,10 @@ static int ends_with(const char* s, const char* suffix) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 3) { fprintf(stderr, "usage: %s scene.(blend|miscene) out.exr [--BPT] [--spp N] [--size WxH] [--max-path N] [--beta B] [--roulette R] [--gpus N]\n", argv[0]); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: %s scene.(blend|miscene) out.exr [--BPT] [--spp N] [--size WxH] [--max-path N] [--beta B] [--roulette R] [--gpus N] [--lamp-scale S]\n", argv[0]); return 2; }
   unsigned width = 512, height = 512, spp = 16, gpus = 1; int bpt = 0;
   mi_pt_params params = {UINT64_MAX >> 1, 1.0f, 0.9f, 1.0f, 3}; /* Options.hpp:30-36 defaults: max_path unlimited, beta 1, roulette 0.9 */
+  mi_blend_options blend_opts = {0.0f, 0.0f, 1.0f, 0u};         /* stock assimp units (include/mi_pt.h) */
   for (int i = 3; i < argc; ++i) {
     if (!strcmp(argv[i], "--BPT")) bpt = 1;
     else if (!strcmp(argv[i], "--PT")) bpt = 0;
@@ -29,10 +31,11 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--max-path") && i + 1 < argc) params.max_path = (uint64_t)atoll(argv[++i]);
     else if (!strcmp(argv[i], "--beta") && i + 1 < argc) params.beta = (float)atof(argv[++i]);
     else if (!strcmp(argv[i], "--roulette") && i + 1 < argc) params.roulette = (float)atof(argv[++i]);
+    else if (!strcmp(argv[i], "--lamp-scale") && i + 1 < argc) blend_opts.lamp_energy_scale = (float)atof(argv[++i]);
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
   mi_scene* scene = NULL;
-  int rc = ends_with(argv[1], ".blend") ? mi_scene_load_blend(argv[1], NULL, &scene) : mi_scene_load(argv[1], &scene);
+  int rc = ends_with(argv[1], ".blend") ? mi_scene_load_blend(argv[1], &blend_opts, &scene) : mi_scene_load(argv[1], &scene);
   if (rc) { fprintf(stderr, "%s\n", mi_pt_last_error()); return 1; }
   if (gpus < 1 || gpus > 64 || (bpt && gpus != 1)) { fprintf(stderr, "--gpus: 1..64, PT only\n"); return 2; }
   mi_pt_handle* hs[64] = {NULL};

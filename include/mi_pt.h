@@ -210,6 +210,23 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
  * MI_PT_MULTI_HOST_MERGE=1), -1 = no call yet.  The in-process form of `master merge` (Options.cpp:1340-1409). */
 int mi_pt_last_multi_merge(void);
 
+/* One PROCESS per GPU: the sum of the per-GPU framebuffers as ONE RCCL collective over xGMI — the in-memory form of `master merge`
+ * (merge_exr, Options.cpp:1340-1409: dst = fst + snd on R, G, B, denom), for hosts that run one rank per device (sample ranges through
+ * sample_offset, or pixel tiles through mi_pt_set_tile_shard; both sum to the one-GPU image).  librccl.so is opened at the first call
+ * (dlopen; MI_PT_RCCL_LIB overrides the name) and is NOT a link-time dependency: without it these calls return MI_ERR_UNSUPPORTED.
+ *   rank 0:      mi_pt_reduce_unique_id(id)  and hands the 128 bytes to the other ranks (file, socket, MPI ... — the host's business)
+ *   every rank:  mi_pt_reduce_init(h, id, rank, world)                   collective: ncclCommInitRank on the handle's device
+ *                mi_pt_render_device(h, ..., rgbn_device, stream, ...)    this rank's share
+ *                mi_pt_reduce_rgbn(h, rgbn_device, W, H, root, stream)     in place, FP32 sum of W*H*4 values; root < 0: all-reduce, else
+ *                                                                          reduce to `root`; stream NULL = the handle's own, synchronised
+ *                mi_pt_reduce_finalize(h)                                 (mi_pt_destroy does it too) */
+#define MI_PT_REDUCE_ID_BYTES 128
+int mi_pt_reduce_available(void); /* 1 if librccl.so could be opened */
+int mi_pt_reduce_unique_id(unsigned char id[MI_PT_REDUCE_ID_BYTES]);
+int mi_pt_reduce_init(mi_pt_handle* h, const unsigned char id[MI_PT_REDUCE_ID_BYTES], uint32_t rank, uint32_t world);
+int mi_pt_reduce_rgbn(mi_pt_handle* h, float* rgbn_sum_device, uint32_t width, uint32_t height, int root, void* stream);
+int mi_pt_reduce_finalize(mi_pt_handle* h);
+
 /* ------------------------------------------------------------------------------------------
  * Frames in flight — the reference's cadence.  Application::render calls Technique::render ONCE PER SAMPLE
  * (Application.cpp:41-79; the batch loop is Framework::runBatch, framework.cpp:426-437) and reads the dvec4 view only
@@ -405,7 +422,11 @@ void mi_camera_pixel_position(const float dir[3], float res_x, float res_y, floa
 typedef struct mi_blend_options {
   float diffuse_scale_by_ref;  /* 1 => diffuse colour *= Material.ref   (fork behaviour unpinned) */
   float specular_scale_by_spec;/* 1 => specular colour *= Material.spec                            */
-  float lamp_energy_scale;     /* exitance = rgb * energy * scale (default 1)                      */
+  float lamp_energy_scale;     /* exitance = rgb * energy * scale (loader.cpp:434-456).  DEFAULT 1 = stock assimp's lamp units: the
+                                  normalised models/TestCase*.blend then average 1.000.  0.01 reproduces the constant of the reference's own
+                                  protocol, `expected = [0.01]*3` (unit_test.py:77-83): the same models average 0.0100 +- 0.0002
+                                  (tests/test_oracle_bpt.py).  Which one the assimp fork implements is unpinned (it cannot be run here); the
+                                  drop-in path is unaffected (there haste::Scene comes from the reference's own loader).  <= 0 means 1. */
   uint32_t reserved;
 } mi_blend_options;
 

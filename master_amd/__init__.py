@@ -120,7 +120,7 @@ assert SURFACE_DTYPE.itemsize == C.sizeof(SurfacePoint) == 64 and NODE_DTYPE.ite
 ABI_SYMBOLS = [
     "mi_pt_create", "mi_pt_destroy", "mi_pt_render", "mi_pt_render_device", "mi_pt_last_error", "mi_pt_abi_version", "mi_pt_build_id",
     "mi_pt_render_frames_async", "mi_pt_render_async", "mi_pt_wait", "mi_pt_wait_add", "mi_view_add_frame", "mi_pt_last_launch",
-    "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_tile_shard", "mi_pt_render_multi", "mi_pt_last_multi_merge", "mi_pt_device_count", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
+    "mi_pt_set_kernel", "mi_pt_get_kernel", "mi_pt_set_tile_shard", "mi_pt_render_multi", "mi_pt_last_multi_merge", "mi_pt_reduce_available", "mi_pt_reduce_unique_id", "mi_pt_reduce_init", "mi_pt_reduce_rgbn", "mi_pt_reduce_finalize", "mi_pt_device_count", "mi_pt_set_instrumented", "mi_pt_intersect", "mi_pt_occluded", "mi_pt_trace_paths", "mi_pt_bvh_info",
     "mi_bpt_render", "mi_bpt_trace_paths", "mi_bpt_set_sky",
     "mi_pt_bvh_download", "mi_pt_blob_download", "mi_camera_setup", "mi_camera_ray_direction", "mi_camera_pixel_position", "mi_scene_load_blend",
     "mi_scene_load", "mi_scene_save", "mi_scene_from_desc", "mi_scene_get_desc", "mi_scene_material_name", "mi_scene_mesh_name",
@@ -155,6 +155,10 @@ def lib():
     L.mi_pt_set_tile_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.mi_pt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, Window, C.c_uint32, C.c_uint64, C.c_uint64, vp, C.POINTER(PtStats)]
     L.mi_pt_device_count.restype = C.c_int
+    L.mi_pt_reduce_unique_id.argtypes = [vp]
+    L.mi_pt_reduce_init.argtypes = [vp, vp, u32, u32]
+    L.mi_pt_reduce_rgbn.argtypes = [vp, vp, u32, u32, C.c_int, vp]
+    L.mi_pt_reduce_finalize.argtypes = [vp]
     L.mi_pt_get_kernel.argtypes = [vp]
     L.mi_pt_set_instrumented.argtypes = [vp, C.c_int]
     L.mi_pt_intersect.argtypes = [vp, u32, vp, vp, vp, vp, vp]
@@ -375,6 +379,20 @@ def load_exr(path):
         lib().mi_free(p)
 
 
+REDUCE_ID_BYTES = 128
+
+
+def reduce_available():
+    return bool(lib().mi_pt_reduce_available())
+
+
+def reduce_unique_id():
+    """mi_pt_reduce_unique_id: the 128 bytes rank 0 hands to the other ranks."""
+    buf = (C.c_ubyte * REDUCE_ID_BYTES)()
+    _check(lib().mi_pt_reduce_unique_id(buf))
+    return bytes(buf)
+
+
 def device_count():
     return lib().mi_pt_device_count()
 
@@ -560,6 +578,17 @@ class PathTracing:
     # -- scene services (parity hooks) -------------------------------------------------------
     def set_kernel(self, kernel):
         _check(lib().mi_pt_set_kernel(self._h, kernel))
+
+    # -- one process per GPU: RCCL sum-reduce of the device framebuffers (merge_exr, Options.cpp:1340-1409) --
+    def reduce_init(self, unique_id, rank, world):
+        buf = (C.c_ubyte * REDUCE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _check(lib().mi_pt_reduce_init(self._h, buf, rank, world))
+
+    def reduce_rgbn(self, device_ptr, width, height, root=-1, stream=None):
+        _check(lib().mi_pt_reduce_rgbn(self._h, C.c_void_p(device_ptr), width, height, int(root), C.c_void_p(stream) if stream else None))
+
+    def reduce_finalize(self):
+        _check(lib().mi_pt_reduce_finalize(self._h))
 
     def set_tile_shard(self, rank, world):
         """Render only the 32x32 tiles {t : t mod world == rank} of the window (Technique.cpp:167); world <= 1 = off."""

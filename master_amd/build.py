@@ -56,22 +56,39 @@ def source_hash(extra_flags=()):
         h.update(b"\0")
     h.update(repr([e if isinstance(e, str) else list(e[:2]) + [e[2]] for e in SOURCES]).encode())
     h.update(repr(list(extra_flags)).encode())
+    h.update(toolchain_id().encode())  # a library built by another compiler / ROCm release is stale too
     return h.hexdigest()[:32]
+
+
+_TOOLCHAIN = None
+
+
+def toolchain_id():
+    """`hipcc --version` of the compiler build() would use (the same image on the GPU box gives the same text), or its path when it cannot be run."""
+    global _TOOLCHAIN
+    if _TOOLCHAIN is None:
+        try:
+            cc = hipcc()
+            _TOOLCHAIN = subprocess.run([cc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60).stdout.decode(errors="replace")
+        except Exception as e:  # noqa: BLE001
+            _TOOLCHAIN = "hipcc unavailable: %r" % (e,)
+    return _TOOLCHAIN
 
 
 def library_build_id(path=None):
     """The id embedded in a built library (read from the bytes of the file, the library is not loaded), or None."""
     path = path or LIB
     try:
-        with open(path, "rb") as fh:
-            blob = fh.read()
-    except OSError:
+        import mmap
+
+        with open(path, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as blob:  # scanned in place, not read into memory
+            i = blob.find(BUILD_ID_TAG)
+            if i < 0:
+                return None
+            j = i + len(BUILD_ID_TAG)
+            return blob[j:j + 32].decode("ascii", "replace")
+    except (OSError, ValueError):
         return None
-    i = blob.find(BUILD_ID_TAG)
-    if i < 0:
-        return None
-    j = i + len(BUILD_ID_TAG)
-    return blob[j:j + 32].decode("ascii", "replace")
 
 
 def needs_build(extra_flags=()):

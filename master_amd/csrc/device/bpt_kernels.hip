@@ -1102,9 +1102,21 @@ hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list,
   else { if (p.wide_nodes == 1u) hipLaunchKernelGGL((bpt_frame<false, 2>), grid, block, lds, stream, p, w); else hipLaunchKernelGGL((bpt_frame<false, 1>), grid, block, lds, stream, p, w); }
   return hipGetLastError();
 }
+// Dynamic LDS of the staged kernels: [scene copy][traversal stack rows].  bpt_trace / bpt_items stage the flat leaf list when p.flat_k is set
+// (flat_scene_f4: 25 K + tables float4), bpt_visibility always the tree copy (blob + one float4 of padding per node and triangle) — with few pair leaves
+// the flat copy is the LARGER one, so the launch reserves the larger of the two in front of the stack rows.
+static size_t bpt_stage_lds_bytes(const RenderParams& p, bool lds_scene) {
+  size_t scene = 0;
+  if (lds_scene) {
+    const size_t tree = size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16;
+    const size_t flat = p.flat_k ? size_t(kFlatLeafF4 * p.flat_k + 18u * p.flat_k + (p.sv.blob_f4 - p.sv.off_mats)) * 16 : 0;
+    scene = tree > flat ? tree : flat;
+  }
+  return scene + size_t(p.stack_entries) * kBlock * 4;
+}
 // staged form: trace + scan (returns the number of connection items of the launch's paths), then items + gather
 hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, bool lds_scene, hipStream_t stream, uint32_t* total_items) {
-  const size_t lds = size_t(p.stack_entries) * kBlock * 4 + (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0);
+  const size_t lds = bpt_stage_lds_bytes(p, lds_scene);
   const dim3 grid((w.lanes + kBlock - 1) / kBlock), block(kBlock);
   hipError_t e = hipMemsetAsync(w.item_offset + w.lanes, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
@@ -1128,7 +1140,7 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
   return hipGetLastError();
 }
 hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, bool lds_scene, uint32_t total_items, hipStream_t stream) {
-  const size_t lds = size_t(p.stack_entries) * kBlock * 4 + (lds_scene ? size_t(p.sv.blob_f4 + p.sv.n_nodes + p.sv.n_tris) * 16 : 0);
+  const size_t lds = bpt_stage_lds_bytes(p, lds_scene);
   if (total_items) {
     hipError_t e;
     if (w.dyn_vis) {

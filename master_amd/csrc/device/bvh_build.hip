@@ -520,7 +520,7 @@ __device__ __forceinline__ uint32_t q_hi(float v, float lo, float inv_step) {
   return uint32_t(q);
 }
 __global__ void k_quantize(uint32_t n_nodes, const mi_bvh_node* __restrict__ nodes, uint4* __restrict__ qnodes, float lx, float ly, float lz,
-                           float ix, float iy, float iz) {
+                           float ix, float iy, float iz, uint32_t pad_cells) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   const mi_bvh_node n = nodes[i];
@@ -531,7 +531,7 @@ __global__ void k_quantize(uint32_t n_nodes, const mi_bvh_node* __restrict__ nod
     for (int k = 0; k < 3; ++k) {
       const uint32_t ql = q_lo(lo[k], glo[k], gis[k]), qh = q_hi(hi[k], glo[k], gis[k]);
       c[k] = (ql + qh) >> 1;
-      const uint32_t ext = (qh - c[k] > c[k] - ql ? qh - c[k] : c[k] - ql) + 1u;
+      const uint32_t ext = (qh - c[k] > c[k] - ql ? qh - c[k] : c[k] - ql) + pad_cells;
       e[k] = ext > 65535u ? 65535u : ext;
     }
     return make_uint4(c[0] | (c[1] << 16), c[2] | (e[0] << 16), e[1] | (e[2] << 16), uint32_t(link));
@@ -552,7 +552,7 @@ __global__ void k_even_depth(uint32_t n_nodes, const mi_bvh_node* __restrict__ n
   flag[x] = (depth & 1u) ^ 1u;
 }
 __global__ void k_collapse4(uint32_t n_nodes, const mi_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ flag_scan, uint4* __restrict__ q4,
-                            float lx, float ly, float lz, float ix, float iy, float iz) {
+                            float lx, float ly, float lz, float ix, float iy, float iz, uint32_t pad_cells) {
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= n_nodes) return;
   const uint32_t me = flag_scan[x];
@@ -570,7 +570,7 @@ __global__ void k_collapse4(uint32_t n_nodes, const mi_bvh_node* __restrict__ no
     for (int k3 = 0; k3 < 3; ++k3) {
       const uint32_t ql = q_lo(lo[k3], glo[k3], gis[k3]), qh = q_hi(hi[k3], glo[k3], gis[k3]);
       c[k3] = (ql + qh) >> 1;
-      const uint32_t ext = (qh - c[k3] > c[k3] - ql ? qh - c[k3] : c[k3] - ql) + 1u;
+      const uint32_t ext = (qh - c[k3] > c[k3] - ql ? qh - c[k3] : c[k3] - ql) + pad_cells;  // 1 unless a camera is far outside the grid (mi_pt_create)
       e[k3] = ext > 65535u ? 65535u : ext;
     }
     a.x = c[0] | (c[1] << 16);
@@ -722,7 +722,7 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
 
 // centre / half-extent copy of the full-precision nodes (ce_box_test<SLACK>, pt_device.h): half extent from the rounded centre, + 2^-20 relative
 // + 2^-21 of the box's own largest coordinate (the roundings of c * inv and e * |inv|; the origin's share is the test's per-ray slack)
-__global__ void k_ce_nodes(uint32_t n_nodes, const float4* __restrict__ nodes, float4* __restrict__ out, float) {
+__global__ void k_ce_nodes(uint32_t n_nodes, const float4* __restrict__ nodes, float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes * 2u) return;
   const uint32_t n = i >> 1, c = i & 1u;
@@ -733,14 +733,14 @@ __global__ void k_ce_nodes(uint32_t n_nodes, const float4* __restrict__ nodes, f
   out[4u * n + 2u * c] = make_float4(cx, cy, cz, lo.w);
   out[4u * n + 2u * c + 1u] = make_float4(ex, ey, ez, hi.w);
 }
-hipError_t ce_nodes(uint32_t n_nodes, const float4* nodes, float4* out, float pad, hipStream_t stream) {
+hipError_t ce_nodes(uint32_t n_nodes, const float4* nodes, float4* out, hipStream_t stream) {
   if (n_nodes == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_ce_nodes, dim3((2u * n_nodes + 255u) / 256u), dim3(256), 0, stream, n_nodes, nodes, out, pad);
+  hipLaunchKernelGGL(k_ce_nodes, dim3((2u * n_nodes + 255u) / 256u), dim3(256), 0, stream, n_nodes, nodes, out);
   return hipGetLastError();
 }
 
 hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, uint4* qnodes4, const float lo[3], const float inv_step[3],
-                          hipStream_t stream) {
+                          uint32_t pad_cells, hipStream_t stream) {
   if (n_nodes == 0) return hipSuccess;
   uint32_t* flag = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&flag), sizeof(uint32_t) * (size_t(n_nodes) + 1 + size_t(n_nodes) / kScanTile + 8));
@@ -749,12 +749,12 @@ hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qno
   hipLaunchKernelGGL(k_even_depth, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, flag);
   scan_exclusive(flag, n_nodes + 1, flag + n_nodes + 1, stream);
   hipLaunchKernelGGL(k_collapse4, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, flag, qnodes4, lo[0], lo[1], lo[2], inv_step[0],
-                     inv_step[1], inv_step[2]);
+                     inv_step[1], inv_step[2], pad_cells);
   e = hipStreamSynchronize(stream);
   hipFree(flag);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_quantize, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, qnodes, lo[0], lo[1], lo[2], inv_step[0],
-                     inv_step[1], inv_step[2]);
+                     inv_step[1], inv_step[2], pad_cells);
   return hipGetLastError();
 }
 

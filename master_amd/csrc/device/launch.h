@@ -14,9 +14,9 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
                      hipStream_t stream);
 
 hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, uint4* qnodes4, const float lo[3], const float inv_step[3],
-                          hipStream_t stream);
+                          uint32_t pad_cells, hipStream_t stream);  // pad_cells: padding of every quantised child box in grid cells (1; more for cameras far outside the grid)
 
-hipError_t ce_nodes(uint32_t n_nodes, const float4* nodes, float4* out, float pad, hipStream_t stream);  // centre / half-extent copy of the full-precision nodes
+hipError_t ce_nodes(uint32_t n_nodes, const float4* nodes, float4* out, hipStream_t stream);  // centre / half-extent copy of the full-precision nodes
 
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene);
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bool count, uint32_t n_blocks, hipStream_t stream);  // mode: 0 image, 1 list, 2 frame (one sample per pixel)

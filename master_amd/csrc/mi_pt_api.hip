@@ -2,6 +2,7 @@
 // LBVH build, render calls, parity hooks.  Everything that computes runs on the GPU; there is no
 // CPU fallback — without a HIP device every compute entry point fails with MI_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -36,6 +37,8 @@ struct mi_pt_handle {
   float4* ce_nodes = nullptr;       // centre / half-extent copy of the full-precision nodes (kernels that read them from HBM: scenes the 16-bit grid is too coarse for)
   float* flat_table = nullptr; uint32_t flat_k = 0, flat_k_mesh = 0; float flat_amax = 0.0f;  // flat_amax: largest |coordinate| the padding of the table's boxes covers  // flat leaf list of small scenes (traverse_flat, pt_device.h): leaf boxes + links, mesh leaves first
   int2* plain_links = nullptr;    // the builder's links of every node in Morton positions (mi_pt_bvh_download); the blob's nodes carry pair leaves
+  void* rccl_comm = nullptr; uint32_t reduce_rank = 0, reduce_world = 0;  // mi_pt_reduce_init: this handle's RCCL communicator (one process per GPU)
+  uint32_t quant_pad_cells = 1;    // padding of the quantised child boxes in grid cells (1 unless a camera is > 2^20 cells away: mi_pt_create)
   bool float_nodes = false;        // HBM-resident kernels read the full-precision nodes: the 16-bit grid is too coarse for this scene
   bool wide_nodes = false;         // the PT megakernel walks the wide nodes (every HBM-resident scene the 16-bit grid is fine enough for; MI_PT_WIDE_NODES=0/1 overrides)
   bool wide_large = false;         // scenes of >= 100 000 triangles: the BPT kernels (two per-lane loops) walk the wide nodes only there
@@ -382,7 +385,18 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->qnodes), size_t(n_nodes ? n_nodes : 1) * 32));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->qnodes4), size_t(n_nodes ? n_nodes : 1) * 64));
-    HIP_TRY(mi::quantize_nodes(n_nodes, reinterpret_cast<const mi_bvh_node*>(h->blob + sv.off_nodes), h->qnodes, h->qnodes4, h->sv.grid_lo, h->sv.grid_inv_step, h->stream));
+    // the quantised walks have no per-ray slack; the padding of a child's half extent (whole cells) must cover the roundings of
+    // (org - grid_lo) * cells_per_unit, org_g * inv and the fmas of wide_child_test, each ~2^-24 |org_g|: together below 2^-22 |org_g| cells.  The grid spans
+    // the scene box, not the cameras, so a camera far outside a thin scene (tiny extent on one axis = tiny cells) can be millions of cells away: the pad is
+    // 1 cell up to 2^20 cells (error <= 1/4 cell) and grows by one cell per further 2^20 (a margin of 4 throughout).  Paths only ever start at a camera or
+    // on a surface inside the box; the parity hooks, whose callers may pass any point, use the FAR variants with the slack term.
+    double far_cells = 65536.0;
+    for (const mi_camera& cam : s.cameras)
+      for (int a = 0; a < 3; ++a) far_cells = std::max(far_cells, std::fabs((double(cam.position[a]) - double(h->sv.grid_lo[a])) * double(h->sv.grid_inv_step[a])));
+    uint32_t pad_cells = 1u + uint32_t(std::min(far_cells * 0x1p-20, 60000.0));
+    if (const char* e = std::getenv("MI_PT_QUANT_PAD")) { const int v = std::atoi(e); if (v >= 1 && v <= 60000) pad_cells = uint32_t(v); }  // tests: shows what the guard prevents
+    h->quant_pad_cells = pad_cells;
+    HIP_TRY(mi::quantize_nodes(n_nodes, reinterpret_cast<const mi_bvh_node*>(h->blob + sv.off_nodes), h->qnodes, h->qnodes4, h->sv.grid_lo, h->sv.grid_inv_step, pad_cells, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->sv.qnodes = h->qnodes; h->sv.qnodes4 = h->qnodes4;
     {  // absolute padding of centre / half-extent boxes (pt_device.h ce_box_test, traverse_flat): rays start within the scene box or at a camera
@@ -394,7 +408,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     }
     // every scene gets the copy (64 B per node): the instrumented / list variants of small scenes read full-precision nodes from HBM too
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ce_nodes), size_t(n_nodes ? n_nodes : 1) * 64));
-    HIP_TRY(mi::ce_nodes(n_nodes, h->blob + sv.off_nodes, h->ce_nodes, h->sv.box_pad, h->stream));
+    HIP_TRY(mi::ce_nodes(n_nodes, h->blob + sv.off_nodes, h->ce_nodes, h->stream));  // padded by 2^-21 of each box's own coordinates; the walk keeps the per-ray slack (ce_box_test<SLACK>)
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->sv.ce_nodes = h->ce_nodes;
     // flat leaf list (small scenes): the box and the link of every leaf link of the tree, pair leaves counting once; the leaves that hold a
@@ -427,11 +441,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
         std::stable_partition(leaves.begin(), leaves.end(), [](const Leaf& l) { return l.mesh; });
         // entry = centre + half extent of the box, the half extent rounded up and padded by 2^-20 of the largest coordinate a ray can start from
         // or a box can have (scene box and cameras): covers the roundings of traverse_flat's three fmas per axis and of v_rcp_f32 (pt_device.h)
-        double amax = 0.0;
-        for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(double(h->info.scene_lo[a])), std::fabs(double(h->info.scene_hi[a]))));
-        for (const mi_camera& cam : s.cameras) for (int a = 0; a < 3; ++a) amax = std::max(amax, std::fabs(double(cam.position[a])));
-        const double pad = amax * 0x1p-20 + 1e-30;
-        h->flat_amax = float(amax);
+        const double pad = double(h->sv.box_pad);  // = flat_amax * 2^-20, computed once above: the table's padding and hooks_use_flat must agree
         const size_t k_pad = (leaves.size() + 3) / 4 * 4;
         std::vector<float> table(k_pad * 8, 0.0f);
         for (size_t k = leaves.size(); k < k_pad; ++k) table[8 * k + 3] = table[8 * k + 4] = table[8 * k + 5] = -1e30f;  // nothing enters a padding entry
@@ -541,6 +551,7 @@ void mi_pt_destroy(mi_pt_handle* h) {
   bool failed = false;
 #define D(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess && !failed) { failed = true; fail(MI_ERR_INTERNAL, std::string("mi_pt_destroy: " #expr ": ") + hipGetErrorString(e_)); } } while (0)
   (void)hipSetDevice(h->device);
+  if (h->rccl_comm) { (void)mi_pt_reduce_finalize(h); }
   if (h->blob) D(hipFree(h->blob));
   if (h->qnodes) D(hipFree(h->qnodes));
   if (h->qnodes4) D(hipFree(h->qnodes4));
@@ -1065,6 +1076,100 @@ int mi_pt_render_multi(mi_pt_handle* const* handles, uint32_t n_handles, uint32_
 }
 
 int mi_pt_last_multi_merge(void) { return g_last_multi_merge; }
+
+// ---- RCCL sum-reduce of the per-GPU framebuffers (one process per GPU; north_star: "RCCL reduce over xGMI of the per-GPU float3 framebuffer") ----
+// The in-memory form of `master merge` (merge_exr, Options.cpp:1340-1409: dst = fst + snd on R, G, B, denom).  librccl.so is looked up at the first
+// call (dlopen), never linked: a host without it gets MI_ERR_UNSUPPORTED and everything else keeps working.  The types below restate the few ABI
+// facts of rccl.h that are used (ncclUniqueId = 128 opaque bytes, ncclFloat32 = 7, ncclSum = 0, ncclSuccess = 0).
+namespace {
+struct RcclId { char internal[MI_PT_REDUCE_ID_BYTES]; };
+struct RcclApi {
+  void* so = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string why;
+};
+RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return &api;
+  tried = true;
+  const char* names[] = {std::getenv("MI_PT_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    if (!n || !*n) continue;
+    api.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (api.so) break;
+    api.why = dlerror();
+  }
+  if (!api.so) return &api;
+#define MI_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.so, name)); if (!api.field) { api.why = std::string("librccl has no ") + name; dlclose(api.so); api.so = nullptr; return &api; }
+  MI_SYM(GetUniqueId, "ncclGetUniqueId") MI_SYM(CommInitRank, "ncclCommInitRank") MI_SYM(AllReduce, "ncclAllReduce") MI_SYM(Reduce, "ncclReduce")
+  MI_SYM(CommDestroy, "ncclCommDestroy") MI_SYM(GetErrorString, "ncclGetErrorString")
+#undef MI_SYM
+  return &api;
+}
+int rccl_fail(const char* what, int rc) { return fail(MI_ERR_INTERNAL, std::string(what) + ": " + (rccl()->GetErrorString ? rccl()->GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")"); }
+}  // namespace
+
+int mi_pt_reduce_available(void) { return rccl()->so ? 1 : 0; }
+
+int mi_pt_reduce_unique_id(unsigned char id[MI_PT_REDUCE_ID_BYTES]) {
+  if (!id) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_reduce_unique_id: null argument");
+  RcclApi* r = rccl();
+  if (!r->so) return fail(MI_ERR_UNSUPPORTED, "RCCL is not available on this host (librccl.so: " + r->why + ")");
+  RcclId u;
+  const int rc = r->GetUniqueId(&u);
+  if (rc) return rccl_fail("ncclGetUniqueId", rc);
+  std::memcpy(id, u.internal, MI_PT_REDUCE_ID_BYTES);
+  return MI_OK;
+}
+
+int mi_pt_reduce_init(mi_pt_handle* h, const unsigned char id[MI_PT_REDUCE_ID_BYTES], uint32_t rank, uint32_t world) {
+  if (!h || !id) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_reduce_init: null argument");
+  if (world == 0 || rank >= world) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_reduce_init: rank must be < world");
+  if (h->rccl_comm) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_reduce_init: the handle has a communicator already (mi_pt_reduce_finalize first)");
+  RcclApi* r = rccl();
+  if (!r->so) return fail(MI_ERR_UNSUPPORTED, "RCCL is not available on this host (librccl.so: " + r->why + ")");
+  HIP_TRY(hipSetDevice(h->device));  // the communicator binds to the current device: one rank per GPU
+  RcclId u;
+  std::memcpy(u.internal, id, MI_PT_REDUCE_ID_BYTES);
+  void* comm = nullptr;
+  const int rc = r->CommInitRank(&comm, int(world), u, int(rank));
+  if (rc) return rccl_fail("ncclCommInitRank", rc);
+  h->rccl_comm = comm; h->reduce_rank = rank; h->reduce_world = world;
+  return MI_OK;
+}
+
+int mi_pt_reduce_rgbn(mi_pt_handle* h, float* rgbn_sum_device, uint32_t width, uint32_t height, int root, void* stream_v) {
+  if (!h || !rgbn_sum_device) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_reduce_rgbn: null argument");
+  if (!h->rccl_comm) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_reduce_rgbn: call mi_pt_reduce_init first");
+  if (width == 0 || height == 0 || uint64_t(width) * height > (1ull << 31)) return fail(MI_ERR_INVALID_ARGUMENT, "bad resolution");
+  if (root >= int(h->reduce_world)) return fail(MI_ERR_INVALID_ARGUMENT, "mi_pt_reduce_rgbn: root must be < world (or negative: all-reduce)");
+  RcclApi* r = rccl();
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : h->stream;
+  const size_t count = size_t(width) * height * 4;  // (R, G, B, denom) per pixel, FP32: 126.6 MiB at 3840x2160
+  const int rc = root < 0 ? r->AllReduce(rgbn_sum_device, rgbn_sum_device, count, 7 /* ncclFloat32 */, 0 /* ncclSum */, h->rccl_comm, stream)
+                          : r->Reduce(rgbn_sum_device, rgbn_sum_device, count, 7, 0, root, h->rccl_comm, stream);
+  if (rc) return rccl_fail(root < 0 ? "ncclAllReduce" : "ncclReduce", rc);
+  if (!stream_v) HIP_TRY(hipStreamSynchronize(stream));  // the handle's own stream: the caller has nothing to wait on
+  return MI_OK;
+}
+
+int mi_pt_reduce_finalize(mi_pt_handle* h) {
+  if (!h) return fail(MI_ERR_INVALID_ARGUMENT, "null handle");
+  if (!h->rccl_comm) return MI_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  const int rc = rccl()->CommDestroy(h->rccl_comm);
+  h->rccl_comm = nullptr; h->reduce_world = 0; h->reduce_rank = 0;
+  if (rc) return rccl_fail("ncclCommDestroy", rc);
+  return MI_OK;
+}
 
 int mi_pt_intersect(mi_pt_handle* h, uint32_t n, const mi_surface_point* origins, const float* directions, mi_surface_point* out_hits,
                     float* out_t, uint32_t* out_prim) {

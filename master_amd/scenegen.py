@@ -284,6 +284,22 @@ def clutter(n_target=150000, seed=2):
 SCENES = {"atrium": atrium, "clutter": clutter}
 
 
+def thin_slab(n_side=48, thickness=0.002, camera_height=3.0, seed=7):
+    """A scene that is thin on one axis — a gently displaced n x n floor (2 n^2 triangles) with a low emitter lying just above it, everything within
+    `thickness` of z = 0 — seen by a camera `camera_height` above it: the camera is camera_height / thickness scene extents (x 65 536 grid cells) outside
+    the box on z.  The case ADVICE r03 names for the quantised node walks (16-bit grid over the scene box only)."""
+    rng = np.random.default_rng(seed)
+    b = FastBuilder()
+    b.add_camera((0.3, -0.2, camera_height), (-0.05, 0.04, -1.0), up=(0, 1, 0), fovx=0.9)
+    grey = b.add_material(material(ma.BSDF_DIFFUSE, diffuse=(0.7, 0.7, 0.65)))
+    shiny = b.add_material(material(ma.BSDF_PHONG, diffuse=(0.3, 0.3, 0.3), specular=(0.4, 0.4, 0.4), power=30.0))
+    half = n_side // 2
+    b.add_tris(*heightfield((-2, -2, 0), (4, 0, 0), (0, 2, 0), (0, 0, 1), n_side, half, 0.4 * thickness, rng), grey)
+    b.add_tris(*heightfield((-2, 0, 0), (4, 0, 0), (0, 2, 0), (0, 0, 1), n_side, half, 0.4 * thickness, rng), shiny)
+    b.add_light((0.2, 0.1, 0.9 * thickness), (0, 0, -1), (0, 1, 0), (1.5, 1.0), (30, 28, 25))
+    return b.build()
+
+
 def load(spec):
     """'atrium', 'atrium:1000000', 'clutter:40000' -> Scene."""
     name, _, n = spec.partition(":")

@@ -149,6 +149,51 @@ def test_c5_workload_tile_shard_properties_and_windows_against_oracle(clutter, r
         np.testing.assert_allclose(img[y0:y0 + h, x0:x0 + w], ref[y0:y0 + h, x0:x0 + w], rtol=1.2e-7)
 
 
+def test_c5_one_rank_renders_its_whole_share(clutter):
+    """BASELINE configs[4] at the size ONE of the eight GPUs really gets: the 32x32 tiles {t : t mod 8 == 3} of the
+    3840x2160 frame x ALL 4096 samples of them = 1/8 of the pixels x 4096 spp = the 512-spp-per-GPU weak-scaling unit of SURVEY 8(e),
+    4.25 G paths in one call (Technique.cpp:167 tiles; the merge is the sum of Options.cpp:1340-1409).  Size-independent properties:
+    denominators, exact path count, numeric errors == missing denominators, the two 2048-sample halves sum to it; plus one window of an
+    owned tile against the oracle at a bounded sample count (pixel index, camera ray and streams depend on the full resolution)."""
+    rank, spp = 3, 4096
+    pt = ma.PathTracing(clutter)
+    pt.set_tile_shard(rank, C5_WORLD)
+    img = pt.render_rgbn(C5_W, C5_H, spp=spp, seed=0x5EED)
+    st = pt.last_stats
+    li = pt.last_launch()
+    mine = madist.tile_owner(C5_W, C5_H, C5_WORLD) == rank
+    n_mine = int(mine.sum())
+    assert n_mine == C5_W * C5_H // C5_WORLD == 1005 * 1024 + 15 * 512  # 1 020 of the 8 160 tiles; 15 of them in the top row, which is 16 pixels high
+    assert np.all(img[~mine] == 0) and np.isfinite(img).all()
+    assert st.num_paths == n_mine * spp == 4246732800
+    den = img[mine][:, 3].astype(np.float64)
+    assert np.all(den <= spp) and np.mean(den == spp) > 0.5 and den.min() >= spp // 2 and den.sum() > 0.999 * n_mine * spp  # glass without a TIR guard drops samples (BSDF.cpp:480-493)
+    assert n_mine * spp - int(den.sum()) == st.numeric_errors  # every dropped sample is a missing denominator (Technique.cpp:222-230)
+    assert st.num_basic_rays > 3 * st.num_paths and st.num_shadow_rays > st.num_paths
+    assert pt.get_kernel() == ma.KERNEL_MEGA_GLOBAL and li.wide_nodes == 1 and li.n_chunks * li.chunk_spp >= spp
+    # the two halves of the sample range sum to the whole (what a resumed or merged render relies on); each framebuffer is one FP32 cast of an FP64 sum
+    lo = pt.render_rgbn(C5_W, C5_H, spp=spp // 2, seed=0x5EED, sample_offset=0).astype(np.float64)
+    paths_lo, err_lo, rays_lo = pt.last_stats.num_paths, pt.last_stats.numeric_errors, pt.last_stats.num_basic_rays
+    hi = pt.render_rgbn(C5_W, C5_H, spp=spp // 2, seed=0x5EED, sample_offset=spp // 2).astype(np.float64)
+    assert paths_lo + pt.last_stats.num_paths == st.num_paths and err_lo + pt.last_stats.numeric_errors == st.numeric_errors
+    assert rays_lo + pt.last_stats.num_basic_rays == st.num_basic_rays
+    parts = lo + hi
+    assert np.array_equal(parts[..., 3], img[..., 3])
+    assert np.all(np.abs(parts - img) <= 1.2e-7 * (np.abs(lo) + np.abs(hi) + np.abs(img)))
+    # one window of an owned tile against the oracle, 8 samples of the same streams
+    tiles_x = (C5_W + 31) // 32
+    ty, tx = divmod(rank + C5_WORLD * 700, tiles_x)
+    x0, y0, w, h = tx * 32 + 4, ty * 32 + 6, 24, 20
+    assert mine[y0:y0 + h, x0:x0 + w].all()
+    got = pt.render_rgbn(C5_W, C5_H, spp=8, seed=0x5EED, window=(x0, y0, w, h))
+    ref = oracle.Oracle(clutter).render_rgbn(C5_W, C5_H, spp=8, seed=0x5EED, window=(x0, y0, w, h))
+    np.testing.assert_allclose(got[y0:y0 + h, x0:x0 + w], ref[y0:y0 + h, x0:x0 + w], rtol=1.2e-7)
+    # the mean of the 4096-sample image over that window agrees with the 8-sample oracle render within its noise (same estimator, more samples)
+    a = img[y0:y0 + h, x0:x0 + w]
+    m4096, m8 = (a[..., :3] / a[..., 3:]).mean(), (ref[y0:y0 + h, x0:x0 + w, :3] / ref[y0:y0 + h, x0:x0 + w, 3:]).mean()
+    assert abs(m4096 - m8) < 0.5 * max(m4096, m8)
+
+
 def test_c5_tile_shards_partition_the_frame_bitwise(clutter):
     """The eight ranks' framebuffers of C5' at full resolution (1 spp) sum to the unsharded render bit for bit: every pixel has one owner."""
     pt = ma.PathTracing(clutter)
@@ -417,3 +462,43 @@ def test_tiny_trees_with_pair_leaves_against_the_oracle(monkeypatch, n):
         assert np.isclose(rad, orad, rtol=0, atol=0, equal_nan=True).all() and np.array_equal(cnt, ocnt), (kernel, env)
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_rccl_reduce_through_the_c_abi_world_of_one(cornell):
+    """the reduce of the per-GPU framebuffers as a call of the library (north_star: "RCCL reduce over xGMI"), for hosts that run one
+    process per GPU — mi_pt_reduce_unique_id / _init / _rgbn / _finalize dlopen librccl.so and run ncclAllReduce / ncclReduce(sum, f32, H*W*4) in
+    place on the device framebuffer of mi_pt_render_device (merge_exr, Options.cpp:1340-1409).  One GPU per box: the communicator has ONE rank here
+    (initialising it and reducing over it is legal and runs the real RCCL code path); the sum over one rank is the identity.  UNMEASURED across GPUs."""
+    import torch
+
+    assert ma.reduce_available()
+    pt = ma.PathTracing(cornell, max_path=5)
+    with pytest.raises(ma.MiError) as e:  # no communicator yet
+        pt.reduce_rgbn(1, 8, 8)
+    assert e.value.code == -1
+    uid = ma.reduce_unique_id()
+    assert len(uid) == ma.REDUCE_ID_BYTES and any(uid)
+    with pytest.raises(ma.MiError):
+        pt.reduce_init(uid, 1, 1)  # rank must be < world
+    pt.reduce_init(uid, 0, 1)
+    with pytest.raises(ma.MiError):
+        pt.reduce_init(uid, 0, 1)  # one communicator per handle
+    w, h = 96, 64
+    fb = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    pt.render_device(fb.data_ptr(), w, h, spp=8, seed=3, stream=stream)
+    before = fb.clone()
+    pt.reduce_rgbn(fb.data_ptr(), w, h, root=-1, stream=stream)   # all-reduce on the caller's stream
+    pt.reduce_rgbn(fb.data_ptr(), w, h, root=0)                   # reduce to rank 0 on the handle's stream (synchronised)
+    torch.cuda.synchronize()
+    assert torch.equal(fb, before) and bool((fb[..., 3] == 8).all())
+    with pytest.raises(ma.MiError):
+        pt.reduce_rgbn(fb.data_ptr(), w, h, root=1)  # root outside the communicator
+    # the C5 payload: 3840 x 2160 x 4 f32 = 126.6 MiB in one call
+    big = torch.ones((2160, 3840, 4), dtype=torch.float32, device="cuda")
+    pt.reduce_rgbn(big.data_ptr(), 3840, 2160)
+    assert bool((big == 1).all())
+    pt.reduce_finalize()
+    pt.reduce_finalize()  # idempotent
+    with pytest.raises(ma.MiError):
+        pt.reduce_rgbn(fb.data_ptr(), w, h)

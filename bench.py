@@ -176,7 +176,7 @@ def collect_live_pmc(specs, timeout_s=300.0, keep_dir=None):
     if not os.path.exists(rocprof):
         return {}, "rocprofv3 not found"
     py = os.path.realpath(sys.executable)
-    base = keep_dir or tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+    base = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
     os.makedirs(base, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     per_launch = [dict() for _ in specs]

@@ -106,10 +106,10 @@ __global__ __launch_bounds__(256) void wf_init(const RenderParams p, const WfSta
   const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
   bool started = false, err = false;
   if (slot < w.P) {
-    uint32_t k = 0, flags = 0; f3 org = F3(0, 0, 0), dir = F3(0, 0, 1); Rng rng; rng.state = 0;
+    uint32_t k = 0, flags = 0; f3 org = F3(0, 0, 0), dir = F3(0, 0, 1); Rng rng; rng.state = 0; rng.inc = 1;
     if (!w.list) w.acc[slot] = make_double4(0.0, 0.0, 0.0, 0.0);
     slot_next_path(p, w, slot, false, F3(0, 0, 0), make_uint2(0u, 0u), k, started, err, flags, org, dir, rng);
-    w.rng[slot] = rng.state;
+    w.rng[slot] = rng_pack(rng);
     w.ray_o[slot] = make_float4(org.x, org.y, org.z, __uint_as_float(flags));
     w.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(k));
     w.st_a[slot] = make_float4(0.f, 0.f, 0.f, 1.0f);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void wf_shade(const RenderParams p, const WfSt
       f3 radiance = F3(sc.x, sc.y, sc.z);
       const bool bounce = (flags & kFlagBounce) != 0u; bool bs_finite = (flags & kFlagFinite) != 0u;
       uint32_t path_size = flags >> 2;
-      Rng rng; rng.state = w.rng[slot];
+      Rng rng = rng_unpack(w.rng[slot]);
       uint2 cnt = w.cnt[slot];
       ++cnt.x;
       Hit h; h.t = hv.x; h.u = hv.y; h.v = hv.z; h.pos = __float_as_uint(hv.w); h.id = h.pos == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void wf_shade(const RenderParams p, const WfSt
         xpos = F3(0, 0, 0); bs_density = 1.0f; tnum = F3(0, 0, 0); new_bounce = false; bs_finite = true; path_size = 0u;
       }
       still = (sflags & kSlotActive) != 0u;
-      w.rng[slot] = rng.state;
+      w.rng[slot] = rng_pack(rng);
       w.ray_o[slot] = make_float4(org.x, org.y, org.z, __uint_as_float(sflags));
       w.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(k));
       w.st_a[slot] = make_float4(xpos.x, xpos.y, xpos.z, bs_density);

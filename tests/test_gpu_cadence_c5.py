@@ -185,7 +185,7 @@ def test_c5_one_rank_renders_its_whole_share(clutter):
     ty, tx = divmod(rank + C5_WORLD * 700, tiles_x)
     x0, y0, w, h = tx * 32 + 4, ty * 32 + 6, 24, 20
     assert mine[y0:y0 + h, x0:x0 + w].all()
-    got = pt.render_rgbn(C5_W, C5_H, spp=8, seed=0x5EED, window=(x0, y0, w, h))
+    got = pt.render_rgbn(C5_W, C5_H, spp=8, seed=0x5EED)  # the sharded frame again (a window would renumber the tiles from its own origin)
     ref = oracle.Oracle(clutter).render_rgbn(C5_W, C5_H, spp=8, seed=0x5EED, window=(x0, y0, w, h))
     np.testing.assert_allclose(got[y0:y0 + h, x0:x0 + w], ref[y0:y0 + h, x0:x0 + w], rtol=1.2e-7)
     # the mean of the 4096-sample image over that window agrees with the 8-sample oracle render within its noise (same estimator, more samples)

@@ -564,11 +564,10 @@ def test_camera_far_outside_a_thin_scene_on_the_quantised_walks(monkeypatch, wid
     pt = ma.PathTracing(s, max_path=5)
     assert pt.get_kernel() == ma.KERNEL_MEGA_GLOBAL
     gr, gc = pt.trace_paths(64, 48, xy, si, seed=13)
-    li = pt.last_launch()
-    assert li.wide_nodes == (1 if wide == "1" else 0)
     same = (gr.view(np.uint32) == orr.view(np.uint32)) | (np.isnan(gr) & np.isnan(orr))
     assert np.array_equal(gc, oc) and same.all(), "mismatching paths: %d" % int((~same.all(1)).sum())
     img = pt.render_rgbn(64, 48, spp=4, seed=13)
+    assert pt.last_launch().wide_nodes == (1 if wide == "1" else 0)  # the quantised records, wide or binary
     ref = oracle.Oracle(s, max_path=5).render_rgbn(64, 48, spp=4, seed=13)
     np.testing.assert_allclose(img, ref, rtol=1.2e-7)
     # BPT walks the same records (eye sub-paths start at the camera)

@@ -37,7 +37,7 @@ def test_models_that_miss_the_constant_are_untuned_copies_of_normalised_ones(par
     (loader.cpp:293-456) or the sun-light terms (BSDF.cpp:164-193, BPT.cpp:192-225) is left to explain — the parent, read and rendered by the same
     code, is on the constant."""
     p = load_scene(parent)
-    img = oracle.Oracle(p, beta=2.0).bpt_render_rgbn(64, 64, spp=32, seed=3, threads=8)
+    img = oracle.Oracle(p, beta=2.0).bpt_render_rgbn(64, 64, spp=256, seed=3, threads=8)  # TestCase30's sun light is a high-variance case: 0.02 of spread at 128 spp
     assert abs(_mean(img) - 1.0) < 0.04, _mean(img)
     for c in copies:
         q = load_scene(c)

@@ -44,6 +44,26 @@ DEF_KERNEL(k_fmac, "v_fmac_f32 %0, %1, %2")
 DEF_KERNEL(k_sub, "v_sub_f32 %0, %0, %1")
 DEF_KERNEL(k_maxf, "v_max_f32 %0, %0, %1")
 DEF_KERNEL(k_xor, "v_xor_b32 %0, %0, %1")
+// r04 candidates: mixed-precision fma (f16 operands read in place: no conversion), byte conversions, sign-bit mask accumulation, 32-bit integer multiplies
+DEF_KERNEL(k_fma_mix, "v_fma_mix_f32 %0, %1, %0, %2 op_sel_hi:[1,0,0]")                        // src0 = f16 (low half of va), src1 / src2 f32
+DEF_KERNEL(k_fma_mix_hi, "v_fma_mix_f32 %0, %1, %0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]")      // src0 = f16 (high half)
+DEF_KERNEL(k_cvt_ubyte0, "v_cvt_f32_ubyte0 %0, %0")
+DEF_KERNEL(k_cvt_ubyte3, "v_cvt_f32_ubyte3 %0, %0")
+DEF_KERNEL(k_cvt_f16, "v_cvt_f32_f16 %0, %0")
+DEF_KERNEL(k_alignbit, "v_alignbit_b32 %0, %0, %1, 31")
+DEF_KERNEL(k_or, "v_or_b32 %0, %0, %1")
+DEF_KERNEL(k_or3, "v_or3_b32 %0, %0, %1, %2")
+DEF_KERNEL(k_addc, "v_addc_co_u32 %0, vcc, %0, %0, vcc")
+DEF_KERNEL(k_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1")
+DEF_KERNEL(k_mul_hi_u32, "v_mul_hi_u32 %0, %0, %1")
+DEF_KERNEL(k_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
+DEF_KERNEL(k_lshrrev, "v_lshrrev_b32 %0, %1, %0")
+DEF_KERNEL(k_rsq, "v_rsq_f32 %0, %0")
+DEF_KERNEL(k_sin, "v_sin_f32 %0, %0")
+DEF_KERNEL(k_div_scale, "v_div_scale_f32 %0, vcc, %0, %1, %2")
+DEF_KERNEL(k_div_fmas, "v_div_fmas_f32 %0, %0, %1, %2")
+DEF_KERNEL(k_div_fixup, "v_div_fixup_f32 %0, %0, %1, %2")
+DEF_KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %2")
 
 template <class K> void run(const char* name, K kern) {
   const int blocks = 256 * 8;  // 256 CUs x 8 blocks of 4 waves = 8 waves per SIMD
@@ -62,5 +82,7 @@ template <class K> void run(const char* name, K kern) {
 int main() {
   RUN(k_fma); RUN(k_fmac); RUN(k_mul); RUN(k_add); RUN(k_sub); RUN(k_min); RUN(k_maxf); RUN(k_max3); RUN(k_med3); RUN(k_cndmask); RUN(k_cndmask64); RUN(k_cmp); RUN(k_cmp_cnd_vcc); RUN(k_cmp_cnd_sgpr); RUN(k_add_cnd_vcc); RUN(k_min_add);
   RUN(k_cvt); RUN(k_cvt_sdwa); RUN(k_addu); RUN(k_and); RUN(k_xor); RUN(k_lshl_add); RUN(k_mov); RUN(k_rcp); RUN(k_sqrt); RUN(k_mad_u32); RUN(k_bfe);
+  RUN(k_fma_mix); RUN(k_fma_mix_hi); RUN(k_cvt_ubyte0); RUN(k_cvt_ubyte3); RUN(k_cvt_f16); RUN(k_alignbit); RUN(k_or); RUN(k_or3); RUN(k_addc); RUN(k_mul_lo_u32); RUN(k_mul_hi_u32);
+  RUN(k_mul_u32_u24); RUN(k_lshrrev); RUN(k_rsq); RUN(k_sin); RUN(k_div_scale); RUN(k_div_fmas); RUN(k_div_fixup); RUN(k_perm);
   return 0;
 }

@@ -354,6 +354,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="map every rank onto the visible GPUs modulo their count (rehearsal only)")
     ap.add_argument("--c5-scene", default="clutter", help="BASELINE configs[4] stand-in for the one-rank share block ('' skips it)")
     ap.add_argument("--c5-size", default="3840x2160x4096", help="WxHxSPP of configs[4]; the block renders rank 0's tiles of world 8 at ALL samples = the 512-spp-per-GPU unit")
+    ap.add_argument("--no-fast-variant", action="store_true", help="skip the second timing of the primary workload through the approximate-arithmetic build (value_fast)")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not start the rocprofv3 --pmc child processes (roofline then replays profiles/traffic.json, pmc_live false)")
     ap.add_argument("--pmc-dir", default="", help="keep the counter CSVs of the live PMC passes here (e.g. gpurun_out/pmc_live)")
     args = ap.parse_args()
@@ -472,6 +473,26 @@ def main():
     elapsed = time.perf_counter() - t0
     li = pt.last_launch()
 
+    # the price of bit-exactness, measured beside the product (VERDICT r03 #2 iii): the same steps through the opt-in approximate-arithmetic build
+    # (MI_PT_FAST=1: v_rcp / v_rsq / v_sqrt / v_sin / v_cos in place of the correctly rounded forms; statistically checked, tests/test_gpu_fast_math.py).
+    # Never `value`.
+    fast = None
+    if world == 1 and rank == 0 and not args.no_fast_variant:
+        os.environ["MI_PT_FAST"] = "1"
+        try:
+            step(0)
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            fsegs = 0
+            for i in range(args.steps):
+                fsegs += step(args.warmup + i).num_basic_rays
+            torch.cuda.synchronize()
+            tf = time.perf_counter() - tf0
+            fast = {"value_fast": fsegs / tf / 1e6, "ms_per_step": tf / args.steps * 1e3, "marked_fast": bool(pt.last_launch().features >> 31),
+                    "arithmetic": "fp32, approximate reciprocals / square roots / sin / cos (v_rcp_f32, v_rsq_f32, v_sqrt_f32, v_sin_f32, v_cos_f32); opt-in MI_PT_FAST=1, not the product's contract"}
+        finally:
+            del os.environ["MI_PT_FAST"]
+
     per_rank = None
     if world > 1:
         dev = "cpu" if gloo_cpu else "cuda"
@@ -528,6 +549,10 @@ def main():
         }
         if per_rank:
             out["per_rank"] = per_rank
+        if fast:
+            out["arithmetic"] = "fp32, correctly rounded (bit-exact against the CPU oracle)"
+            out["value_fast"] = fast["value_fast"]
+            out["fast_variant"] = fast
     del pt
     if rank == 0 and world == 1 and not args.no_hbm_workload:
         out["hbm_workload"] = hbm_workload(ma, torch, args, seed, args.hbm_scene, args.hbm_size, live_pmc=live_pmc)

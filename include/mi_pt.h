@@ -271,7 +271,7 @@ typedef struct mi_pt_launch_info {
   uint32_t chunk_spp;       /* samples per pixel in a chunk                                                   */
   uint32_t lds_bytes;       /* dynamic LDS per workgroup                                                      */
   uint32_t wide_nodes;      /* 0 = 32-byte quantised binary nodes, 1 = 64-byte wide nodes, 2 = 64-byte float nodes */
-  uint32_t features;        /* kFeat* bits of the kernel variant                                              */
+  uint32_t features;        /* kFeat* bits of the kernel variant; bit 31: the approximate-arithmetic build ran (MI_PT_FAST=1, opt-in) */
   uint32_t lds_tables;      /* 1: materials, lights and the light CDF were staged into LDS by every workgroup */
   uint32_t frame_tiles_per_wave; /* > 0: frame mode (spp == 1): paths write the framebuffer directly, a wave owns this many 8x8 tiles */
   uint32_t frames;               /* frame mode: frames of the launch */

@@ -17,6 +17,7 @@ LIB = os.path.join(HERE, "libmi_pt.so")
 SOURCES = [
     "mi_pt_api.hip",
     "device/pt_kernels.hip",
+    ("device/pt_kernels.hip", ["-DMI_PT_FAST=1"], "fastmath"),                                     # opt-in variant: v_rcp / v_rsq / v_sqrt / v_sin / v_cos instead of the IEEE forms
     "device/bvh_build.hip",
     "device/wf_kernels.hip",
     "device/bpt_kernels.hip",                                                                       # every BSDF, any beta

@@ -18,6 +18,10 @@ hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qno
 
 hipError_t ce_nodes(uint32_t n_nodes, const float4* nodes, float4* out, hipStream_t stream);  // centre / half-extent copy of the full-precision nodes
 
+namespace fastmath {  // the megakernel built with -DMI_PT_FAST: approximate reciprocal / square root / sin / cos (vecmath.h); opt-in, never the default
+size_t pt_lds_bytes(const RenderParams& p, bool lds_scene);
+hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bool count, uint32_t n_blocks, hipStream_t stream);
+}
 size_t pt_lds_bytes(const RenderParams& p, bool lds_scene);
 hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bool count, uint32_t n_blocks, hipStream_t stream);  // mode: 0 image, 1 list, 2 frame (one sample per pixel)
 hipError_t launch_finalize(const double* partial, float* rgbn, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w,

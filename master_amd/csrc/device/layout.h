@@ -52,7 +52,7 @@ struct DevLight {  // 6 float4
   float radiance[3]; uint32_t material_id;  // exitance / pi (AreaLights.hpp:54)
   float lsdf_density;                    // weight / area        (AreaLights.cpp:152)
   float area_density;                    // 1 / area             (AreaLights.cpp:135)
-  uint32_t diffuse; uint32_t pad;
+  uint32_t diffuse; float inv_cd;        // 1 / (area_density * weight): the reciprocal _connect divides the radiance by (PT.cpp:117-119), formed once on the host
 };
 
 struct RenderParams {
@@ -83,6 +83,7 @@ struct RenderParams {
   // PathTracing members (PT.hpp:24-28)
   uint32_t max_path, min_subpath;
   float beta, roulette, lights;
+  float inv_roulette;      // 1 / roulette as one IEEE division on the host: throughput / roulette = throughput * (1 / roulette) by the contract (PT.cpp:92)
   // outputs
   double* partial;        // [n_chunks][height*width][4] (r, g, b sums, count)
   unsigned long long* counters;  // [9]: basic rays, shadow rays, numeric errors, paths, + instrumented: nodes/tris visited by closest-hit rays, by shadow rays, closest-hit rays that hit

@@ -23,7 +23,7 @@ constexpr int kFeatPhong = 1, kFeatDelta = 2, kFeatPow = 4, kFeatLights = 8, kFe
 // accepted candidate — two IEEE divisions, ~24 instructions, taken out of a leaf body that runs for 2.8 lanes of 64 on average).
 struct Hit { float t, u, v; uint32_t id, pos; float den; };
 __device__ __forceinline__ void finish_hit(Hit& h) {
-  if (h.id != 0xFFFFFFFFu) { h.u = h.u / h.den; h.v = h.v / h.den; }
+  if (h.id != 0xFFFFFFFFu) { h.u = mi_div(h.u, h.den); h.v = mi_div(h.v, h.den); }
 }
 
 // SurfacePoint (SurfacePoint.hpp:37-63)
@@ -58,11 +58,11 @@ MI_DEV bool tri_test(const float4* __restrict__ tris, uint32_t pos, f3 org, f3 d
   if (!(U >= 0.0f) || !(V >= 0.0f) || !(U + V <= absden)) return false;
   const float T = dot(ng, C) * sgn;
   if (!(absden * 0.0f < T)) return false;
-  const float t = T / absden;
-  if (ANY) {
-    if (t <= h.t) { h.id = id; return true; }
+  if (ANY) {  // rtcOccluded on the segment of Scene::occluded (Scene.cpp:165-175: tfar = 1, exactly): RN(T / |den|) <= 1 <=> T <= |den| for floats — no division
+    if (T <= absden) { h.id = id; return true; }
     return false;
   }
+  const float t = mi_div(T, absden);
   if (t < h.t || (t == h.t && id < h.id)) {
     h.t = t; h.u = U; h.v = V; h.den = absden; h.id = id; h.pos = pos;
     return true;
@@ -104,10 +104,9 @@ struct RayBox { f3 inv, oi; float slack; };
 MI_DEV RayBox make_raybox(f3 org, f3 dir) {
   RayBox r;
   const float big = 1e18f;  // direction component == 0: a finite stand-in keeps 0 * inf out of the slabs
-  float ix = __builtin_amdgcn_rcpf(dir.x), iy = __builtin_amdgcn_rcpf(dir.y), iz = __builtin_amdgcn_rcpf(dir.z);
-  ix = fabsf(ix) < big ? ix : copysignf(big, dir.x);
-  iy = fabsf(iy) < big ? iy : copysignf(big, dir.y);
-  iz = fabsf(iz) < big ? iz : copysignf(big, dir.z);
+  // v_rcp_f32(+-0) = +-inf keeps the sign of the zero, so the median with +-big is the round-3 "fabsf(i) < big ? i : copysignf(big, d)" in one instruction
+  const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dir.x), -big, big), iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dir.y), -big, big),
+              iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dir.z), -big, big);
   r.inv = F3(ix, iy, iz);
   r.oi = org * r.inv;
   r.slack = (fabsf(r.oi.x) + fabsf(r.oi.y) + fabsf(r.oi.z)) * 2.5e-7f;
@@ -462,13 +461,15 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
         const bool seen = mode == 1u || (gmask & (1u << MI_ENTITY_MESH)) != 0u;
         pop = true;
         if (seen && den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absden && absden * 0.0f < T) {
-          const float t = T / absden;
-          if (mode == 2u) {
-            if (t <= 1.0f) { atomicOr((unsigned int*)&d.occl[owner >> 5], 1u << (owner & 31u)); mode = 0u; pop = false; }
-          } else if (t < h.t || (t == h.t && (h.pos == 0xFFFFFFFFu || id < __float_as_uint(tris[3 * h.pos + 2].y)))) {
-            // (t, id) minimum; on an exact tie (rare) the best hit's id is read back.  t == h.t == infinity with nothing hit yet (|den| so
-            // small that T / |den| overflows) is a hit, as in tri_test: its id is smaller than the initial 0xFFFFFFFF
-            h.t = t; h.pos = uint32_t(~node) & kLeafPosMask;
+          if (mode == 2u) {  // t = T / |den| <= 1 <=> T <= |den| (tri_test): the shadow rays of the loop need no division
+            if (T <= absden) { atomicOr((unsigned int*)&d.occl[owner >> 5], 1u << (owner & 31u)); mode = 0u; pop = false; }
+          } else {
+            const float t = mi_div(T, absden);
+            if (t < h.t || (t == h.t && (h.pos == 0xFFFFFFFFu || id < __float_as_uint(tris[3 * h.pos + 2].y)))) {
+              // (t, id) minimum; on an exact tie (rare) the best hit's id is read back.  t == h.t == infinity with nothing hit yet (|den| so
+              // small that T / |den| overflows) is a hit, as in tri_test: its id is smaller than the initial 0xFFFFFFFF
+              h.t = t; h.pos = uint32_t(~node) & kLeafPosMask;
+            }
           }
         }
         if ((uint32_t(node) & kLeafPairBit) == 0u && mode != 0u) { node = int((uint32_t(node) | kLeafPairBit) - 1u); pop = false; }  // ~(pos + 1), a single leaf
@@ -547,12 +548,12 @@ MI_DEV bool flat_tri(const float4 a, const float4 b, const float4 c, uint32_t id
   if (ANY && (idw >> 30) != uint32_t(MI_ENTITY_MESH)) return false;  // Scene.cpp:42,173: shadow rays see mesh geometry only
   if (MASKED && !((1u << (idw >> 30)) & ray_mask)) return false;
   if (!(den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absden && absden * 0.0f < T)) return false;
-  const float t = T / absden;
   const uint32_t id = idw & 0x3FFFFFFFu;
-  if (ANY) {
-    if (t <= h.t) { h.id = id; return true; }
+  if (ANY) {  // tfar of a shadow ray is exactly 1 (Scene.cpp:165-175): RN(T / |den|) <= 1 <=> T <= |den| (tri_test above; tests/test_box_forms.py)
+    if (T <= absden) { h.id = id; return true; }
     return false;
   }
+  const float t = mi_div(T, absden);
   if (t < h.t || (t == h.t && id < h.id)) {
     h.t = t; h.u = U; h.v = V; h.den = absden; h.id = id; h.pos = slot;
     return true;
@@ -578,6 +579,9 @@ MI_DEV void traverse_flat(const float4* __restrict__ leaves, cfloat* __restrict_
   // three full-rate instructions where max(tnear, 0), v_cmp, v_cndmask and v_lshl_or (all half rate on gfx950) stood: 16 -> 6 issue cycles of the
   // 42 a box cost, for the 16 + ~10 boxes of every trip.  (tfar = -0.0 counts as a miss: the padding of the half extents puts the exit of a
   // box that holds a hit strictly in front of the origin.)  The mask collects MISS bits; it starts as all ones so that bits above the table stay misses.
+  // Measured and removed (profiles/r04/ab_c2_instruction_cuts.txt): a box around every group of four entries, tested first, with a wave-wide skip of a
+  // group no lane enters — C2 -5 % (24 390 -> 23 180 Msamples/s, VALU per segment 2 200 -> 2 310): the lanes of a wave hold paths at every bounce, some
+  // lane enters every group on nearly every trip, and the group tests are pure addition.
   uint32_t miss = 0xFFFFFFFFu;
   for (uint32_t g = K4; g-- != 0u;) {  // wave-uniform: four boxes per trip, scalar operands
     cfloat* t = table + 32u * g;
@@ -725,8 +729,8 @@ MI_DEV BQuery bsdf_query(const Material& m, const Surf& sf, f3 incident, f3 outg
 
 // sample_lambert (Sample.inl:52-60)
 MI_DEV f3 sample_lambert(Rng& g, f3 omega) {
-  const float y = sqrtf(rng_f(g)) * gsign(omega.y);
-  const float r = sqrtf(1.0f - y * y);
+  const float y = mi_sqrt(rng_f(g)) * gsign(omega.y);
+  const float r = mi_sqrt(1.0f - y * y);
   float sn, cs;
   sincos_2pi(rng_f(g), &sn, &cs);
   return F3(r * cs, y, r * sn);
@@ -737,8 +741,8 @@ MI_DEV f3 sample_phong(Rng& g, f3 omega, float power) {
   m.c1 = F3(-omega.x, omega.y, -omega.z);
   m.c2 = normalize(F3(0.0f, 1.0f, 0.0f) - m.c1 * m.c1.y);
   m.c0 = normalize(cross(m.c1, m.c2));
-  const float y = mi_powf(rng_f(g), 1.0f / (power + 1.0f));
-  const float r = sqrtf(1.0f - y * y);
+  const float y = mi_powf(rng_f(g), mi_rcp(power + 1.0f));
+  const float r = mi_sqrt(1.0f - y * y);
   float sn, cs;
   sincos_2pi(rng_f(g), &sn, &cs);
   return mulmv(m, F3(r * cs, y, r * sn));
@@ -761,23 +765,23 @@ MI_DEV BSample bsdf_sample(const Material& m, Rng& g, const Surf& sf, f3 omega) 
     const float same_side = dot(omega, sf.gnormal) * dot(r.omega, sf.gnormal) > 0.0f ? 1.0f : 0.0f;
     r.q = phong_query_local(m, lo, d, same_side);
   } else if ((FEAT & kFeatDelta) && m.type == MI_BSDF_REFLECTION) {  // BSDF.cpp:450-465
-    const float v = 1.0f / lo.y;
+    const float v = mi_rcp(lo.y);
     r.q.throughput = F3(v, v, v);
     r.omega = to_world(sf, F3(-lo.x, lo.y, -lo.z));
     r.q.density = 1.0f; r.q.densityRev = 1.0f; r.q.finite = 0;
   } else if ((FEAT & kFeatDelta) && m.type == MI_BSDF_TRANSMISSION) {  // BSDF.cpp:467-504
-    const float ext_over_int = m.ior_external / m.ior_internal;
+    const float ext_over_int = mi_div(m.ior_external, m.ior_internal);
     f3 o;
     if (lo.y > 0.f) {
       const float eta = ext_over_int;
-      const float yy = sqrtf(1 - eta * eta * (1 - lo.y * lo.y));
+      const float yy = mi_sqrt(1 - eta * eta * (1 - lo.y * lo.y));
       o = ((lo - F3(0.0f, lo.y, 0.0f)) * -eta) - F3(0.0f, yy, 0.0f);
     } else {
-      const float eta = 1.0f / ext_over_int;
-      const float yy = sqrtf(1 - eta * eta * (1 - lo.y * lo.y));
+      const float eta = mi_rcp(ext_over_int);
+      const float yy = mi_sqrt(1 - eta * eta * (1 - lo.y * lo.y));
       o = ((lo - F3(0.0f, lo.y, 0.0f)) * -eta) + F3(0.0f, yy, 0.0f);
     }
-    const float v = 1.0f / fabsf(o.y);
+    const float v = mi_rcp(fabsf(o.y));
     r.q.throughput = F3(v, v, v);
     r.omega = to_world(sf, o);
     r.q.density = 1.0f; r.q.densityRev = 1.0f; r.q.finite = 0;
@@ -834,27 +838,27 @@ MI_DEV f3 connect_prepare(const float4* __restrict__ sb, const SceneView& sv, co
   const f3 lnormal = xyz(l2);
   const f3 xl = x.position - lpos;
   const float len2 = dot(xl, xl);  // == dot(lpos - x, lpos - x) bit for bit
-  const f3 omega = xl * (1.0f / sqrtf(len2));
+  const f3 omega = xl * mi_rsqrt(len2);
   // light-side "BSDF": front side only; sun lights contribute nothing through NEE
   const float front = (__float_as_uint(l5.z) != 0u && dot(lnormal, omega) > 0.0f) ? 1.0f : 0.0f;
   has_shadow = !(front * 3.0f < MI_FLT_EPSILON);
   if (!has_shadow) return F3(0, 0, 0);
   const BQuery eb = bsdf_query<FEAT>(mat, x, -omega, x_omega);
   // Edge(light.surface, eye.surface, omega)
-  const float distSqInv = 1.0f / len2;
+  const float distSqInv = mi_rcp(len2);
   const float fCos = fabsf(dot(omega, x.tangent.c1));
   const float bCos = fabsf(dot(omega, lnormal));
   const float fG = distSqInv * fCos;
   const float bG = distSqInv * bCos;
-  const float cd = l5.y * l0.w;  // area_density * light_density
-  const float wInv = powb<FEAT>(eb.densityRev * bG, beta) / powb<FEAT>(cd, beta) + 1.0f;
+  const float cd = l5.y * l0.w;  // area_density * light_density (AreaLights.cpp:135-139)
+  const float wInv = mi_div(powb<FEAT>(eb.densityRev * bG, beta), powb<FEAT>(cd, beta)) + 1.0f;
   // Scene::occluded's end points (Scene.cpp:153-167); signs from the unnormalised direction
   const f3 direction = lpos - x.position;
   const f3 ao = x.position + (x.gnormal * (dot(x.gnormal, direction) > 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   const f3 at = lpos + (lnormal * (dot(lnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   ray.org = ao;
   ray.dir = at - ao;
-  f3 r = xyz(l4) / cd;
+  f3 r = xyz(l4) * l5.w;  // radiance / cd = radiance * (1 / cd) by the contract; 1 / cd is a constant of the light, divided once on the host (DevLight::inv_cd: same IEEE division)
   r = r * x_throughput;
   r = r * eb.throughput;
   r = r * bCos;

@@ -21,7 +21,16 @@
 
 #include "pt_device.h"
 
-namespace mi {
+// MI_PT_FAST (build.py compiles this file a second time with it): the megakernel with the hardware's approximate reciprocal / square root / sin / cos
+// (vecmath.h) in namespace mi::fastmath; only launch_megakernel and pt_lds_bytes exist there.  Opt-in at run time (MI_PT_FAST=1), never the default.
+#ifdef MI_PT_FAST
+#define MI_PT_NS_BEGIN namespace mi { namespace fastmath {
+#define MI_PT_NS_END } }
+#else
+#define MI_PT_NS_BEGIN namespace mi {
+#define MI_PT_NS_END }
+#endif
+MI_PT_NS_BEGIN
 
 MI_DEV uint32_t rank_in(uint64_t mask) {  // number of set bits of `mask` below this lane
   return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
           // new vertex z = hit (PT.cpp:53-68); Edge(eye[prv], eye[itr], -dir)
           const f3 omega = -dir;
           const f3 d = xpos - sp.position;
-          const float distSqInv = 1.0f / dot(d, d);
+          const float distSqInv = mi_rcp(dot(d, d));
           const float fCos = fabsf(dot(omega, sp.tangent.c1));
           const float fG = distSqInv * fCos;
           if (l1norm(tnum) < MI_FLT_EPSILON) {
@@ -327,19 +336,20 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
               const Material lm = load_material(tb, tv, sp.material_id);
               f3 le; float dens;
               query_lsdf<FEAT>(tb, tv, light0, lm.light_id, omega, le, dens);
-              float wInv = powb<FEAT>(dens, p.beta) / powb<FEAT>(fG * bs_density, p.beta) + 1.0f;
+              float wInv = mi_div(powb<FEAT>(dens, p.beta), powb<FEAT>(fG * bs_density, p.beta)) + 1.0f;
               if (!bs_finite) wInv = 1.0f;
               radiance = radiance + (le * ztp) / wInv;
               org = nudge(sp.position, sp.gnormal, dir);
             } else {
               // Russian roulette (PT.cpp:86-94)
               const uint32_t path_size = ps_pix & 0x03FFFFFFu;
-              const float roul = path_size < p.min_subpath ? 1.0f : p.roulette;
+              const bool free_ride = path_size < p.min_subpath;
+              const float roul = free_ride ? 1.0f : p.roulette;
               const float uu = rng_f(rng);
               if (roul < uu) {
                 terminate = true;
               } else {
-                x_throughput = ztp / roul;
+                x_throughput = ztp * (free_ride ? 1.0f : p.inv_roulette);  // ztp / roul = ztp * (1 / roul): the reciprocal is a launch constant (host, same IEEE division)
                 if (path_size != 0x03FFFFFFu) ++ps_pix;
                 if (path_size + 1u > p.max_path) terminate = true; else do_vertex = true;  // PT.cpp:40
               }
@@ -460,6 +470,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   }
 }
 
+#ifndef MI_PT_FAST
 // rgbn[pixel] = sum over chunks (fixed order) of the FP64 partials, cast to FP32 — the
 // payload handed to the caller / to the RCCL reduce ([H][W][4], row 0 = bottom).
 __global__ __launch_bounds__(256) void pt_finalize(const double* __restrict__ partial, float4* __restrict__ rgbn, uint32_t width,
@@ -590,6 +601,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded_flat(SceneView sv, const fl
   out[i] = h.id != 0xFFFFFFFFu ? 0.f : 1.f;
 }
 
+#endif  // !MI_PT_FAST
 #ifdef MI_ONE_KERNEL
 // register-budget experiments (tools/one_kernel.sh): compile ONE instantiation and stop — seconds instead of minutes
 template __global__ void pt_megakernel<MI_ONE_KERNEL>(const RenderParams p);
@@ -608,6 +620,11 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
   const bool large = p.wide_nodes == 1u;
   const bool list = mode == 1;
   const bool six = lds <= (160u * 1024u) / MI_DYN_W_HI;  // six workgroups of this LDS size fit a CU
+#ifdef MI_PT_FAST
+  if (count || list || mode != 0) return hipErrorInvalidValue;  // the fast-arithmetic build holds the image-mode variants only
+#define MI_MODE2(a, b) (b)
+#else
+#define MI_MODE2(a, b) (mode == 2 ? (a) : (b))
   if (!lds_scene && p.wide_nodes == 2u && ((count || list) && !(p.dyn_traverse && p.lds_tables))) {  // full-precision 64-byte nodes from HBM: scenes whose triangles are small against the 16-bit grid
     if (count) fn = pt_megakernel<false, 0, true, MI_WAVES_HBM, 0>;
     else fn = pt_megakernel<false, 1, false, MI_WAVES_HBM, 0>;
@@ -624,19 +641,21 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
     fn = p.wide_nodes == 2u ? pt_megakernel<false, 1, false, 5, 0, kFeatAll, true, true, true>
                             : (large ? pt_megakernel<false, 1, false, 5, 2, kFeatAll, true, true, true> : pt_megakernel<false, 1, false, 5, 1, kFeatAll, true, true, true>);
   else if (list) fn = lds_scene ? pt_megakernel<true, 1, false, MI_WAVES_LDS, 0> : (large ? pt_megakernel<false, 1, false, MI_WAVES_HBM_LARGE, 2> : pt_megakernel<false, 1, false, MI_WAVES_HBM, 1>);
-  else {
+  else
+#endif
+  {
     // the compiled feature set that covers the scene: any combination of Phong lobes and mirrors / glass with beta in {1, 2}, or everything
 #define MI_PICK4(L, M, W, Q, S, B) (f2 == 0 ? pt_megakernel<L, M, false, W, Q, (B) | 0, S> : f2 == 1 ? pt_megakernel<L, M, false, W, Q, (B) | 1, S> : \
                                     f2 == 2 ? pt_megakernel<L, M, false, W, Q, (B) | 2, S> : pt_megakernel<L, M, false, W, Q, (B) | 3, S>)
 #define MI_PICK(L, M, W, Q, S) (feat == kFeatAll ? pt_megakernel<L, M, false, W, Q, kFeatAll, S> : (feat & kFeatLights) ? MI_PICK4(L, M, W, Q, S, kFeatLights) : MI_PICK4(L, M, W, Q, S, 0))
-#define MI_PICK_MODE(L, W, Q, S) (mode == 2 ? MI_PICK(L, 2, W, Q, S) : MI_PICK(L, 0, W, Q, S))
+#define MI_PICK_MODE(L, W, Q, S) MI_MODE2(MI_PICK(L, 2, W, Q, S), MI_PICK(L, 0, W, Q, S))
 #define MI_PICK4T(M, W, Q, B) (f2 == 0 ? pt_megakernel<false, M, false, W, Q, (B) | 0, true, true> : f2 == 1 ? pt_megakernel<false, M, false, W, Q, (B) | 1, true, true> : \
                                f2 == 2 ? pt_megakernel<false, M, false, W, Q, (B) | 2, true, true> : pt_megakernel<false, M, false, W, Q, (B) | 3, true, true>)
 #define MI_PICKT(M, W, Q) (feat == kFeatAll ? pt_megakernel<false, M, false, W, Q, kFeatAll, true, true> : (feat & kFeatLights) ? MI_PICK4T(M, W, Q, kFeatLights) : MI_PICK4T(M, W, Q, 0))
 #define MI_PICK4TD(M, W, Q, B) (f2 == 0 ? pt_megakernel<false, M, false, W, Q, (B) | 0, true, true, true> : f2 == 1 ? pt_megakernel<false, M, false, W, Q, (B) | 1, true, true, true> : \
                                 f2 == 2 ? pt_megakernel<false, M, false, W, Q, (B) | 2, true, true, true> : pt_megakernel<false, M, false, W, Q, (B) | 3, true, true, true>)
 #define MI_PICKTD(M, W, Q) (feat == kFeatAll ? pt_megakernel<false, M, false, W, Q, kFeatAll, true, true, true> : (feat & kFeatLights) ? MI_PICK4TD(M, W, Q, kFeatLights) : MI_PICK4TD(M, W, Q, 0))
-#define MI_PICK_HBM(W, Q) (p.lds_tables ? (p.dyn_traverse ? (six ? (mode == 2 ? MI_PICKTD(2, MI_DYN_W_HI, Q) : MI_PICKTD(0, MI_DYN_W_HI, Q)) : (mode == 2 ? MI_PICKTD(2, 5, Q) : MI_PICKTD(0, 5, Q))) : (mode == 2 ? MI_PICKT(2, W, Q) : MI_PICKT(0, W, Q))) : MI_PICK_MODE(false, W, Q, true))
+#define MI_PICK_HBM(W, Q) (p.lds_tables ? (p.dyn_traverse ? (six ? MI_MODE2(MI_PICKTD(2, MI_DYN_W_HI, Q), MI_PICKTD(0, MI_DYN_W_HI, Q)) : MI_MODE2(MI_PICKTD(2, 5, Q), MI_PICKTD(0, 5, Q))) : MI_MODE2(MI_PICKT(2, W, Q), MI_PICKT(0, W, Q))) : MI_PICK_MODE(false, W, Q, true))
     const int feat = (p.features & uint32_t(kFeatPow)) ? kFeatAll : int(p.features);  // a general beta is rare: only the general variant has pow
     const int f2 = feat & 3;
 #define MI_PICK4D(M, B) (f2 == 0 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 0, false, false, true> : f2 == 1 ? pt_megakernel<true, M, false, MI_WAVES_LDS, 0, (B) | 1, false, false, true> : \
@@ -645,15 +664,16 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
 #define MI_PICK4F(M, B) (f2 == 0 ? pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, (B) | 0, false, false, false, true> : f2 == 1 ? pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, (B) | 1, false, false, false, true> : \
                          f2 == 2 ? pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, (B) | 2, false, false, false, true> : pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, (B) | 3, false, false, false, true>)
 #define MI_PICKF(M) (feat == kFeatAll ? pt_megakernel<true, M, false, MI_WAVES_FLAT, 0, kFeatAll, false, false, false, true> : (feat & kFeatLights) ? MI_PICK4F(M, kFeatLights) : MI_PICK4F(M, 0))
-    if (lds_scene && p.flat_k) fn = mode == 2 ? MI_PICKF(2) : MI_PICKF(0);  // flat leaf list
+    if (lds_scene && p.flat_k) fn = MI_MODE2(MI_PICKF(2), MI_PICKF(0));  // flat leaf list
     else
-    if (lds_scene && p.dyn_traverse && p.stack_in_lds) fn = mode == 2 ? MI_PICKD(2) : MI_PICKD(0);  // unified traversal with dynamic fetch
+    if (lds_scene && p.dyn_traverse && p.stack_in_lds) fn = MI_MODE2(MI_PICKD(2), MI_PICKD(0));  // unified traversal with dynamic fetch
     else
     if (lds_scene) fn = p.stack_in_lds ? MI_PICK_MODE(true, MI_WAVES_LDS, 0, false) : MI_PICK_MODE(true, MI_WAVES_LDS, 0, true);  // shallow tree: stack without the spill path
     else if (p.wide_nodes == 2u) fn = MI_PICK_HBM(MI_WAVES_HBM, 0);
     else if (large) fn = MI_PICK_HBM(MI_WAVES_HBM_LARGE, 2);
     else fn = MI_PICK_HBM(MI_WAVES_HBM, 1);
 #undef MI_PICK_HBM
+#undef MI_MODE2
 #undef MI_PICKF
 #undef MI_PICK4F
 #undef MI_PICKTD
@@ -672,6 +692,7 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
   return hipGetLastError();
 }
 
+#ifndef MI_PT_FAST
 hipError_t launch_finalize(const double* partial, float* rgbn, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w,
                            uint32_t h, uint32_t n_chunks, hipStream_t stream) {
   const uint32_t n = width * height;
@@ -712,6 +733,7 @@ hipError_t launch_occluded_flat(const SceneView& sv, const float* table, uint32_
   return hipGetLastError();
 }
 
+#endif  // !MI_PT_FAST
 #endif  // MI_ONE_KERNEL
 
-}  // namespace mi
+MI_PT_NS_END  // namespace mi (:: fastmath)

@@ -21,18 +21,35 @@ struct m33 { f3 c0, c1, c2; };  // column-major like glm::mat3
 
 #define MI_DEV __device__ __forceinline__
 
+// The four operations the arithmetic contract spells as IEEE: reciprocal, quotient, square root, reciprocal square root.  The product computes
+// them correctly rounded (what the CPU oracle and the reference's glm / libm compute): ~10, ~10, ~16 and ~26 instructions on gfx950.  MI_PT_FAST
+// (a second build of pt_kernels.hip, opt-in at run time through MI_PT_FAST=1, never the default and never what the parity tests run) replaces them
+// by the 1-ulp hardware approximations v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 and sin / cos(2 pi u) by v_sin_f32 / v_cos_f32 (input in turns): the
+// price of bit-exactness, measured (VERDICT r03 #2 iii; bench.py `value_fast`).
+#ifdef MI_PT_FAST
+MI_DEV float mi_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+MI_DEV float mi_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+MI_DEV float mi_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+MI_DEV float mi_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+MI_DEV float mi_rcp(float x) { return 1.0f / x; }
+MI_DEV float mi_div(float a, float b) { return a / b; }
+MI_DEV float mi_sqrt(float x) { return sqrtf(x); }
+MI_DEV float mi_rsqrt(float x) { return 1.0f / sqrtf(x); }
+#endif
+
 MI_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 MI_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
 MI_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
 MI_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
 MI_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
-MI_DEV f3 operator/(f3 a, float s) { const float r = 1.0f / s; return F3(a.x * r, a.y * r, a.z * r); }  // contract: v / s = v * (1 / s)
+MI_DEV f3 operator/(f3 a, float s) { const float r = mi_rcp(s); return F3(a.x * r, a.y * r, a.z * r); }  // contract: v / s = v * (1 / s)
 MI_DEV f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
 MI_DEV float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 MI_DEV f3 cross(f3 a, f3 b) {
   return F3(fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y)));
 }
-MI_DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+MI_DEV f3 normalize(f3 a) { return a * mi_rsqrt(dot(a, a)); }
 MI_DEV f3 madd(f3 a, f3 b, float s) { return F3(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)); }
 MI_DEV float l1norm(f3 a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z); }
 MI_DEV float gsign(float x) { return float((0.0f < x) - (x < 0.0f)); }
@@ -51,6 +68,10 @@ MI_DEV f3 mulvm(f3 v, const m33& m) { return F3(dot(m.c0, v), dot(m.c1, v), dot(
 // reduction on u, which is exact in binary floating point, then odd/even polynomials on
 // |theta| <= pi/4.  Max error ~1.5e-7 absolute.  The oracle states the same formula.
 MI_DEV void sincos_2pi(float u, float* s, float* c) {
+#ifdef MI_PT_FAST
+  *s = __builtin_amdgcn_sinf(u); *c = __builtin_amdgcn_cosf(u);  // v_sin_f32 / v_cos_f32 take their argument in turns
+  return;
+#endif
   float k = floorf(fmaf(u, 4.0f, 0.5f));  // nearest quadrant 0..4
   float r = fmaf(k, -0.25f, u);           // exact: u - k/4 in [-1/8, 1/8]
   float t = r * 6.28318530717958647692f;  // theta

@@ -202,6 +202,7 @@ void fill_pt(const mi_pt_handle* h, mi::RenderParams& p) {
   p.max_path = mp >= (1ull << 20) ? (1u << 20) : uint32_t(mp);
   p.min_subpath = h->params.min_subpath;
   p.beta = h->params.beta; p.roulette = h->params.roulette; p.lights = h->params.lights;
+  { volatile float inv = 1.0f / p.roulette; p.inv_roulette = inv; }
   // what the scene needs of the BSDF code (kFeat* in pt_device.h); MI_PT_PLAIN_KERNEL=0 keeps the general variant (A/B)
   uint32_t f = 0;
   for (const mi_material& m : h->scene.materials) {
@@ -347,6 +348,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
       d.lsdf_density = weight / area;
       d.area_density = 1.0f / area;
       d.diffuse = l.diffuse;
+      { volatile float cd = d.area_density * weight; volatile float inv = 1.0f / cd; d.inv_cd = inv; }  // connect_prepare: cd = l5.y * l0.w, one rounding each
       cdf[i + 1] = cdf[i] + weight;
     }
     HIP_TRY(hipMemcpy(h->blob + sv.off_lights, dl.data(), dl.size() * sizeof(mi::DevLight), hipMemcpyHostToDevice));
@@ -786,7 +788,12 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   HIP_TRY(hipMemsetAsync(ev.counters, 0, mi::kCounterWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ev.ev0, stream));
   if (sharded) HIP_TRY(hipMemsetAsync((*ev.partial), 0, size_t(p.n_chunks) * width * height * 32, stream));  // pixels of other ranks' tiles
-  HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), 0, h->instrumented, uint32_t(n_blocks), stream));
+  // MI_PT_FAST=1 (opt-in, measurement): the megakernel built with the hardware's approximate reciprocal / square root / sin / cos — NOT bit-exact against
+  // the oracle, checked statistically only (tests/test_gpu_fast_math.py); the instrumented variant and every other mode stay exact
+  const char* fast_env = std::getenv("MI_PT_FAST");
+  const bool fast = fast_env && std::atoi(fast_env) != 0 && !h->instrumented;
+  if (fast) HIP_TRY(mi::fastmath::launch_megakernel(p, use_lds_scene(h), 0, false, uint32_t(n_blocks), stream));
+  else HIP_TRY(mi::launch_megakernel(p, use_lds_scene(h), 0, h->instrumented, uint32_t(n_blocks), stream));
   {
     mi_pt_launch_info& li = h->last;
     li.kernel = use_lds_scene(h) ? MI_PT_KERNEL_MEGA_LDS : MI_PT_KERNEL_MEGA_GLOBAL;
@@ -796,6 +803,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     li.partial_bytes = uint64_t(p.n_chunks) * win.w * win.h * 32ull;
     li.scene_bytes = uint64_t(h->sv.blob_f4) * 16ull + uint64_t(h->sv.n_nodes) * 160ull;
   }
+  if (fast) h->last.features |= 0x80000000u;
   HIP_TRY(hipEventRecord(ev.ev1, stream));
   HIP_TRY(mi::launch_finalize((*ev.partial), rgbn_sum_device, width, height, win.x0, win.y0, win.w, win.h, p.n_chunks, stream));
   HIP_TRY(hipEventRecord(ev.ev2, stream));
@@ -1098,7 +1106,17 @@ RcclApi* rccl() {
   static bool tried = false;
   if (tried) return &api;
   tried = true;
-  const char* names[] = {std::getenv("MI_PT_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  // The RCCL that belongs to the HIP runtime THIS library runs on comes first: the librccl next to the loaded libamdhip64 (dladdr).  A process may hold a
+  // second ROCm stack (a Python host with a framework that bundles its own librccl / libhsa-runtime64): an RCCL bound to the other stack's HSA instance
+  // finds that one uninitialised ("no ROCm-capable device is detected").
+  std::string beside_hip[2];
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) { dir.resize(slash); beside_hip[0] = dir + "/librccl.so"; beside_hip[1] = dir + "/librccl.so.1"; }
+  }
+  const char* names[] = {std::getenv("MI_PT_RCCL_LIB"), beside_hip[0].c_str(), beside_hip[1].c_str(), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
   for (const char* n : names) {
     if (!n || !*n) continue;
     api.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);

@@ -133,7 +133,7 @@ def test_product_does_not_link_or_import_the_oracle():
                 if "dlopen" in txt:  # the one dlopen of the product: librccl.so for mi_pt_reduce_* (never a link-time dependency), by these names only
                     assert f == "mi_pt_api.hip" and txt.count("dlopen(") == 1
                     names = re.search(r"const char\* names\[\] = \{([^}]*)\}", txt).group(1)
-                    assert "rccl" in names and "oracle" not in names and re.findall(r'"([^"]+)"', names) == ["MI_PT_RCCL_LIB", "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"]
+                    assert "rccl" in names and "oracle" not in names and re.findall(r'"([^"]+)"', names) == ["MI_PT_RCCL_LIB", "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"] and names.count("beside_hip") == 2
 
 
 def _build_c_example(tmp_path):

@@ -133,3 +133,18 @@ def test_quantised_children_never_lose_a_box_the_ray_enters():
         assert not lost.any(), (tmax, int(lost.sum()), o[lost][:2], d[lost][:2], lo[lost][:2], hi[lost][:2])
     bare = ce_test(c, np.maximum(qh - cq, cq - ql).astype(F), o, inv, F(np.inf))  # without the extra cell: thousands of boxes lost
     assert (exact_enters(lo, hi, o, d, np.inf) & ~bare & np.isfinite(d).all(1)).sum() > 1000
+
+
+def test_any_hit_on_a_unit_segment_needs_no_division():
+    """Scene::occluded casts a SEGMENT: tnear 0, tfar 1 exactly (Scene.cpp:165-175), and rtcOccluded accepts a triangle with t = T / |den| <= tfar.
+    For floats T, |den| > 0 the correctly rounded quotient is <= 1 exactly when T <= |den| (T > |den| puts the quotient at least one ulp-ratio above 1,
+    beyond the rounding midpoint), so the any-hit tests of the device compare T with |den| and skip the IEEE division (pt_device.h tri_test / flat_tri /
+    traverse_dyn, r04).  Checked here on every neighbour of |den| within 4 ulps over 29 decades, powers of two included."""
+    rng = np.random.default_rng(1)
+    with np.errstate(all="ignore"):
+        for scale in (1e-30, 1e-10, 1e-3, 1.0, 1e3, 1e20):
+            d = (rng.random(400_000).astype(np.float32) + np.float32(1e-3)) * np.float32(scale)
+            d = np.concatenate([d, np.float32(scale) * np.float32(2.0) ** rng.integers(-3, 3, 500).astype(np.float32)])
+            for k in range(-4, 5):
+                t = (d.view(np.uint32).astype(np.int64) + k).astype(np.uint32).view(np.float32)
+                assert np.array_equal(t / d <= np.float32(1.0), t <= d)

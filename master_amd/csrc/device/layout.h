@@ -46,13 +46,15 @@ struct SceneView {
 
 struct DevLight {  // 6 float4
   float position[3]; float weight;       // AreaLights::_weights[i] (AreaLights.cpp:199-209)
-  float t0[3]; float area;               // tangent[0]; size.x * size.y
+  float t0[3]; float inv_cd;             // tangent[0]; 1 / (area_density * weight): the reciprocal _connect divides the radiance by (PT.cpp:117-119), formed once on the
+                                         // host (same IEEE division).  In this slot because connect_prepare reads t0 anyway: a fourth word of l5 cost the 80-register
+                                         // kernels of HBM-resident scenes four more spilled dwords (profiles/r04/ab_c2_instruction_cuts.txt)
   float t1[3]; float size_x;             // tangent[1] = emission normal
   float t2[3]; float size_y;             // tangent[2]
   float radiance[3]; uint32_t material_id;  // exitance / pi (AreaLights.hpp:54)
   float lsdf_density;                    // weight / area        (AreaLights.cpp:152)
   float area_density;                    // 1 / area             (AreaLights.cpp:135)
-  uint32_t diffuse; float inv_cd;        // 1 / (area_density * weight): the reciprocal _connect divides the radiance by (PT.cpp:117-119), formed once on the host
+  uint32_t diffuse; uint32_t pad;
 };
 
 struct RenderParams {

@@ -858,7 +858,7 @@ MI_DEV f3 connect_prepare(const float4* __restrict__ sb, const SceneView& sv, co
   const f3 at = lpos + (lnormal * (dot(lnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   ray.org = ao;
   ray.dir = at - ao;
-  f3 r = xyz(l4) * l5.w;  // radiance / cd = radiance * (1 / cd) by the contract; 1 / cd is a constant of the light, divided once on the host (DevLight::inv_cd: same IEEE division)
+  f3 r = xyz(l4) * l1.w;  // radiance / cd = radiance * (1 / cd) by the contract; 1 / cd is a constant of the light, divided once on the host (DevLight::inv_cd: same IEEE division)
   r = r * x_throughput;
   r = r * eb.throughput;
   r = r * bCos;

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
   // path_size (PT.cpp:38) in the low 26 bits, pixel-in-tile in the high 6: one register.  A path of 2^26 edges
   // cannot occur (roulette survival 0.9^n); the counter saturates there and max_path >= 2^26 means unlimited.
   uint32_t ps_pix = 0;
-  Rng rng; rng.state = 0; rng.inc = 1;
+  Rng rng; rng.state = 0;
   uint32_t item_id = 0;
   uint32_t n_basic = 0, n_shadow = 0, n_err = 0, n_paths = 0;  // wave-uniform (ballot popcounts): live in SGPRs
   uint32_t path_basic = 0, path_shadow = 0;  // LIST mode per-path counts

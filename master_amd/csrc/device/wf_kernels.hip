@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void wf_init(const RenderParams p, const WfSta
   const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
   bool started = false, err = false;
   if (slot < w.P) {
-    uint32_t k = 0, flags = 0; f3 org = F3(0, 0, 0), dir = F3(0, 0, 1); Rng rng; rng.state = 0; rng.inc = 1;
+    uint32_t k = 0, flags = 0; f3 org = F3(0, 0, 0), dir = F3(0, 0, 1); Rng rng; rng.state = 0;
     if (!w.list) w.acc[slot] = make_double4(0.0, 0.0, 0.0, 0.0);
     slot_next_path(p, w, slot, false, F3(0, 0, 0), make_uint2(0u, 0u), k, started, err, flags, org, dir, rng);
     w.rng[slot] = rng_pack(rng);

@@ -340,7 +340,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
       const float area = l.size[0] * l.size[1];
       const float weight = area * l1(l.exitance) * total_inv;
       std::memcpy(d.position, l.position, 12); d.weight = weight;
-      std::memcpy(d.t0, l.tangent, 12); d.area = area;
+      std::memcpy(d.t0, l.tangent, 12);
       std::memcpy(d.t1, l.tangent + 3, 12); d.size_x = l.size[0];
       std::memcpy(d.t2, l.tangent + 6, 12); d.size_y = l.size[1];
       for (int k = 0; k < 3; ++k) d.radiance[k] = l.exitance[k] * 0.318309886183790671537767526745028724f;  // AreaLights.hpp:54

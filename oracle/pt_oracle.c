@@ -42,7 +42,7 @@
  *
  * Random numbers: the reference PT cannot be seeded (Options.cpp:821-833; every tile reseeds
  * from std::random_device, Technique.cpp:170-174), so streams are defined here, not copied:
- * a 32-bit PCG (O'Neill 2014, RXS-M-XS 32) with a per-pixel increment, seeded per path by a 32-bit finaliser over (seed, pixel, sample).
+ * SplitMix32 (a Weyl sequence through a 32-bit finaliser), seeded per path by the same finaliser over (seed, pixel, sample).
  * The GPU path uses the same definition, so per-path results are comparable 1:1.
  *
  * Build: gcc -O2 -std=c11 -ffp-contract=off -fPIC -shared -pthread (see Makefile).
@@ -239,9 +239,9 @@ ORC_API float orc_asinf(float x) { return mi_asinf(x); }
 
 /* ------------------------------------------------------------------ RNG (defined here) */
 /* The reference draws from mt19937 and cannot be seeded (Sample.hpp:9-31, Options.cpp:821-833): the stream is this build's definition, keyed on
- * (seed, pixel, sample).  Round 4: 32-bit state + odd increment, PCG-RXS-M-XS-32 draws (two 32-bit multiplies each), seeded by two rounds of the
- * "lowbias32" finaliser; the pixel's hash is the stream's increment.  master_amd/csrc/device/rng.h states the same; tests/golden/rng_kat.json pins both. */
-typedef struct { uint32_t state, inc; } rng_t;
+ * (seed, pixel, sample).  Round 4: one 32-bit word — SplitMix32 draws (Weyl step 0x9E3779B9, "lowbias32" finaliser: two 32-bit multiplies), seeded by
+ * two rounds of the same finaliser.  master_amd/csrc/device/rng.h states the same; tests/golden/rng_kat.json pins both. */
+typedef struct { uint32_t state; } rng_t;
 static inline uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x21F0AAADu;
   x ^= x >> 15; x *= 0x735A2D97u;
@@ -249,17 +249,13 @@ static inline uint32_t mix32(uint32_t x) {
 }
 static inline rng_t rng_seed(uint64_t seed, uint32_t pixel_index, uint64_t sample_index) {
   const uint32_t a = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9E3779B9u));
-  const uint32_t hp = mix32(a ^ pixel_index);
   rng_t r;
-  r.inc = hp | 1u;
-  r.state = mix32(hp ^ (uint32_t)sample_index ^ ((uint32_t)(sample_index >> 32) * 0x9E3779B1u));
+  r.state = mix32(mix32(a ^ pixel_index) ^ (uint32_t)sample_index ^ ((uint32_t)(sample_index >> 32) * 0x9E3779B1u));
   return r;
 }
 static inline uint32_t rng_u32(rng_t* r) {
-  const uint32_t old = r->state;
-  r->state = old * 747796405u + r->inc;
-  const uint32_t w = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
-  return (w >> 22u) ^ w;
+  r->state += 0x9E3779B9u;
+  return mix32(r->state);
 }
 /* uniform in [0,1): top 24 bits (random_generator_t::sample<float>, Sample.inl:259-262) */
 static inline float rng_f(rng_t* r) { return (float)(rng_u32(r) >> 8) * 0x1p-24f; }

@@ -51,7 +51,7 @@ def main():
     }, open(os.path.join(G, "reference_constants.json"), "w"), indent=1)
 
     # (b) oracle regression pins
-    rng = {"source": "oracle regression pin (stream definition of this build, round 4: PCG-RXS-M-XS-32 seeded by lowbias32 over seed / pixel / sample)", "cases": []}
+    rng = {"source": "oracle regression pin (stream definition of this build, round 4: SplitMix32 seeded by lowbias32 over seed / pixel / sample)", "cases": []}
     for seed, pixel, sample in [(0, 0, 0), (0x5EED, 131071, 1023), (2 ** 63 + 12345, 0xFFFFFFFF, 2 ** 40 + 7)]:
         v = oracle.rng_floats(seed, pixel, sample, 8)
         rng["cases"].append({"seed": seed, "pixel": pixel, "sample": sample, "floats_hex": [float(x).hex() for x in v]})

@@ -858,7 +858,10 @@ MI_DEV f3 connect_prepare(const float4* __restrict__ sb, const SceneView& sv, co
   const f3 at = lpos + (lnormal * (dot(lnormal, direction) < 0.0f ? 1.0f : -1.0f)) * 0.0001f;
   ray.org = ao;
   ray.dir = at - ao;
-  f3 r = xyz(l4) * l1.w;  // radiance / cd = radiance * (1 / cd) by the contract; 1 / cd is a constant of the light, divided once on the host (DevLight::inv_cd: same IEEE division)
+  // radiance / cd = radiance * (1 / cd) by the contract.  One light (its record arrives through scalar loads): 1 / cd is a constant of the light, divided once on
+  // the host (DevLight::inv_cd: the same IEEE division).  Several lights (the record is read per lane): the division stays — the fourth word of l1 cost the
+  // 80-register kernels four more spilled dwords per lane (profiles/r04/ab_c2_instruction_cuts.txt).  Same bits either way.
+  f3 r = (FEAT & kFeatLights) ? xyz(l4) / cd : xyz(l4) * l1.w;
   r = r * x_throughput;
   r = r * eb.throughput;
   r = r * bCos;

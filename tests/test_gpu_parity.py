@@ -277,7 +277,10 @@ def test_full_size_stand_ins_properties(label, spec, w, h, spp):
     second = pt.render_rgbn(w, h, spp=spp // 2, seed=0x5EED, sample_offset=spp // 2); n2 = (pt.last_stats.num_basic_rays, pt.last_stats.num_shadow_rays)
     assert (n1[0] + n2[0], n1[1] + n2[1]) == (st.num_basic_rays, st.num_shadow_rays)
     assert np.array_equal(first[..., 3] + second[..., 3], img[..., 3])
-    np.testing.assert_allclose(first.astype(np.float64) + second, img, rtol=6e-7, atol=1e-30)  # three FP32 roundings of FP64 sums
+    # three FP32 roundings of FP64 sums.  A mirror seen from behind its shading normal contributes with a negative sign (ReflectionBSDF: throughput
+    # 1 / omega.y, BSDF.cpp:450-465), so the halves may cancel: the bound is relative to the parts, not to their sum
+    f64, s64 = first.astype(np.float64), second.astype(np.float64)
+    assert np.all(np.abs(f64 + s64 - img) <= 1.2e-7 * (np.abs(f64) + np.abs(s64) + np.abs(img)))
     win = (w // 2 - 16, h // 2 - 12, 32, 24)
     a = pt.render_rgbn(w, h, spp=2, seed=3, window=win); r = oracle.Oracle(s).render_rgbn(w, h, spp=2, seed=3, window=win)
     x0, y0, ww, hh = win

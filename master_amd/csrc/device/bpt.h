@@ -7,6 +7,8 @@
 
 namespace mi {
 
+constexpr uint32_t kBptStepF4 = 16;  // float4 per path of BptState::step_state
+
 struct BptState {
   uint32_t lanes;          // paths of this launch (one lane each)
   uint32_t first;          // image mode: first lane's index in tile order; list mode: first list item
@@ -30,6 +32,13 @@ struct BptState {
   uint32_t dyn_vis;        // 1: bpt_items reads `occl` instead of walking the item's ray itself
   uint32_t vis_th;         // idle lanes of a walking wave that trigger a refill from the ray list
   uint32_t vis_wide;       // node records of the visibility walk: 1 = 64-byte wide quantised, 0 = 32-byte binary quantised (scenes read from HBM)
+  // tracing stage as uniform steps (r04, scenes read from HBM): a path's coroutine state between two closest-hit rays, its pending ray and that ray's hit,
+  // the lists of paths that have a ray in flight (ping-pong) with their counts
+  float4* step_state;      // [lanes][kBptStepF4]
+  float4* step_rays;       // [lanes][2]: (origin | geometry mask), (direction | -)
+  float4* step_hits;       // [lanes]: (t, u, v, Morton position or 0xFFFFFFFF = miss)
+  uint32_t* step_active[2];  // [lanes] path indices
+  uint32_t* step_count;    // [2] entries of step_active[k]
   float* eye;              // [frames][H][W][3] eye images (Technique::_eye_image)
   double* light;           // [frames][H][W][3] light images (Technique::_light_image)
   float sphere[4];         // scene bounding sphere (loader.cpp:408-432) for the emitters' bounded cosine sampling
@@ -43,6 +52,7 @@ struct BptState {
   namespace ns {                                                                                                                                  \
   hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list, hipStream_t stream);                                            \
   hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, bool lds_scene, hipStream_t stream, uint32_t* total_items);      \
+  hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool list, hipStream_t stream, uint32_t* total_items, uint32_t* rounds); \
   hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, bool lds_scene, uint32_t total_items, hipStream_t stream);     \
   hipError_t bpt_launch_commit(const RenderParams& p, const BptState& w, hipStream_t stream);                                                      \
   }
@@ -54,15 +64,16 @@ MI_BPT_DECLARE(bpt_plain)  // no Phong lobes, no mirrors / glass, beta in {0, 1,
 struct BptLaunchers {
   hipError_t (*frame)(const RenderParams&, const BptState&, bool, hipStream_t);
   hipError_t (*trace)(const RenderParams&, const BptState&, bool, bool, hipStream_t, uint32_t*);
+  hipError_t (*trace_steps)(const RenderParams&, const BptState&, bool, hipStream_t, uint32_t*, uint32_t*);
   hipError_t (*connect)(const RenderParams&, const BptState&, bool, bool, uint32_t, hipStream_t);
   hipError_t (*commit)(const RenderParams&, const BptState&, hipStream_t);
 };
 // the set compiled for `features` (RenderParams::features, kFeat* bits; for BPT kFeatPow means beta not in {0, 1, 2})
 inline BptLaunchers bpt_launchers(uint32_t features) {
   features &= 7u;  // the BPT kernels are not specialised on the number of lights
-  if (features == 0u) return {bpt_plain::bpt_launch_frame, bpt_plain::bpt_stage_trace, bpt_plain::bpt_stage_connect, bpt_plain::bpt_launch_commit};
-  if ((features & 4u) == 0u) return {bpt_fixed::bpt_launch_frame, bpt_fixed::bpt_stage_trace, bpt_fixed::bpt_stage_connect, bpt_fixed::bpt_launch_commit};
-  return {bpt_all::bpt_launch_frame, bpt_all::bpt_stage_trace, bpt_all::bpt_stage_connect, bpt_all::bpt_launch_commit};
+  if (features == 0u) return {bpt_plain::bpt_launch_frame, bpt_plain::bpt_stage_trace, bpt_plain::bpt_stage_trace_steps, bpt_plain::bpt_stage_connect, bpt_plain::bpt_launch_commit};
+  if ((features & 4u) == 0u) return {bpt_fixed::bpt_launch_frame, bpt_fixed::bpt_stage_trace, bpt_fixed::bpt_stage_trace_steps, bpt_fixed::bpt_stage_connect, bpt_fixed::bpt_launch_commit};
+  return {bpt_all::bpt_launch_frame, bpt_all::bpt_stage_trace, bpt_all::bpt_stage_trace_steps, bpt_all::bpt_stage_connect, bpt_all::bpt_launch_commit};
 }
 
 }  // namespace mi

@@ -487,7 +487,7 @@ MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, void* sta
 #define MI_BPT_TRACE_WAVES 4
 #endif
 #ifndef MI_BPT_ITEMS_WAVES
-#define MI_BPT_ITEMS_WAVES 6  // tools/ab_bpt_stage_waves.sh, 512^2 x 32: items 3/4/5/6 waves = 53.9/56.6/54.4/55.4 ms (Cornell), 280/281/282/272 ms (LivingRoomLit);
+#define MI_BPT_ITEMS_WAVES 6  // tools/sessions/ab_bpt_stage_waves.sh, 512^2 x 32: items 3/4/5/6 waves = 53.9/56.6/54.4/55.4 ms (Cornell), 280/281/282/272 ms (LivingRoomLit);
 #endif                        // trace 3/4/5 waves = 61.4/56.6/62.4 and 303/281/286 ms
 template <bool LIST, int QN>
 __global__ __launch_bounds__(kBlock, MI_BPT_TRACE_WAVES) void bpt_trace(const RenderParams p, const BptState w) {

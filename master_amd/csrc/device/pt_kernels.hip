@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
     if (pool_next > pool_end) pool_next = pool_end;
   } else if (FRAME) {
     // wave = (group of frame_tiles_per_wave tiles) x (chunk of frame_chunk consecutive frames of the launch); consecutive waves share the tiles.
-    // Measured on C2 (tools/spp_scaling.py, profiles/r02/cadence.txt): a launch wants >= 2-3 rounds of waves AND >= 2 paths per lane.
+    // Measured on C2 (tools/sessions/spp_scaling.py, profiles/r02/cadence.txt): a launch wants >= 2-3 rounds of waves AND >= 2 paths per lane.
     const uint32_t n_fc = (p.frame_count + p.frame_chunk - 1u) / p.frame_chunk, n_tiles = p.tiles_x * p.tiles_y;
     const uint32_t group = logical_wave / n_fc, fc = logical_wave - group * n_fc;
     chunk = fc * p.frame_chunk;                                                              // first frame of the wave

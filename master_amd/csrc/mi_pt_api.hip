@@ -722,7 +722,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     uint32_t tiles_per_wave = 1;  // measured on C2 (profiles/r02/cadence.txt): with several frames per launch one tile per wave keeps the chip full
     if (const char* t = std::getenv("MI_PT_FRAME_TILES")) { const int v = std::atoi(t); if (v >= 1 && v <= 256) tiles_per_wave = uint32_t(v); }
     // frames per wave: a wave that owns its tile in 2-4 frames runs 2-4 paths per lane (steady state: 0.17 ms per 512 x 512 frame with one
-    // path per lane, 0.119 with two, 0.104 with four, 0.095 with sixteen; tools/spp_scaling.py) as long as the launch keeps several
+    // path per lane, 0.119 with two, 0.104 with four, 0.095 with sixteen; tools/sessions/spp_scaling.py) as long as the launch keeps several
     // rounds of waves (6 144 are resident): measured best at 4 for batches of 4-8 frames (profiles/r02/cadence.txt)
     uint32_t frame_chunk = n_frames >= 4 ? 4u : n_frames;
     if (const char* t = std::getenv("MI_PT_FRAME_CHUNK")) { const int v = std::atoi(t); if (v >= 1 && v <= int(mi::kMaxFramesPerLaunch)) frame_chunk = uint32_t(v); }
@@ -760,7 +760,7 @@ int render_impl(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   const uint64_t max_chunks = spp >= 32 ? spp / 16 : 1;
   if (n_chunks > max_chunks) n_chunks = max_chunks;
   // r02: a short render (Technique::render with a few samples per call) would leave the chip part empty — 16 spp at 512^2 is 4 096 waves for 6 144 slots,
-  // 2.6 ms = 0.16 ms per sample against 0.095 in a long launch.  Four samples per wave cost 9 % per sample (tools/spp_scaling.py) but fill it:
+  // 2.6 ms = 0.16 ms per sample against 0.095 in a long launch.  Four samples per wave cost 9 % per sample (tools/sessions/spp_scaling.py) but fill it:
   // below four rounds of waves the chunks go down to 4 samples.
   if (n_chunks * n_tiles < 24576 && spp >= 8) {
     const uint64_t want = (24576 + n_tiles - 1) / n_tiles, cap = spp / 4;

@@ -11,6 +11,10 @@
 // The scene is read from HBM through the quantised nodes; no LDS-resident variant yet.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cmath>
+#include <algorithm>
+
 #include "pt_device.h"
 #include "bpt.h"
 
@@ -624,6 +628,279 @@ __global__ __launch_bounds__(kBlock, MI_BPT_TRACE_WAVES) void bpt_trace(const Re
   if (o && (threadIdx.x & 63u) == 0 && p.counters) atomicAdd(&p.counters[15], (unsigned long long)o);
 }
 
+// =====================================================================================================================
+// Stage A as UNIFORM STEPS (r04; scenes read from HBM).  bpt_trace above walks a whole light sub-path and a whole eye sub-path per lane: a wave runs as
+// long as its longest sub-path (3.5 vertices on average, dozens at the tail) and every scene_intersect is a per-lane tree walk inside that loop —
+// 9 % of the lanes of an issued instruction were active (profiles/r03/pmc_bpt_livingroom.txt).  Here a path is a coroutine that is suspended at each
+// closest-hit ray:  bpt_step  resumes every path that has a hit waiting, runs it to its next ray (roulette, BSDF sample, vertex records, emission
+// terms — bounded, traversal-free work) and appends it to the list of paths in flight;  bpt_closest  walks the rays of that list.  Rounds repeat until
+// the list is empty.  Same draws in the same order, same arithmetic, same records as bpt_trace: everything downstream (scan, items, gather) is unchanged.
+//
+// Path state between two rays (kBptStepF4 = 16 float4): [0] phase, rng, L, E  [1] items, emission terms, directional NEE, rays  [2] size, prv, k, flags
+// (1 at_camera, 2 b.finite)  [3..9] prev (record format of rec_store_l: LVert in the light phase, EVert in the eye phase)  [10..13] unused  [14] b.omega | b.density
+// [15] b.throughput | b.densityRev.  The pending ray (nudged origin | geometry mask, direction) and its hit live in step_rays / step_hits.
+constexpr uint32_t kStepStart = 0, kStepLight = 1, kStepEye = 2;
+#ifndef MI_BPT_STEP_WAVES
+#define MI_BPT_STEP_WAVES 4
+#endif
+#ifndef MI_BPT_STEP_ROUNDS
+#define MI_BPT_STEP_ROUNDS 24  // rounds of (walk, step) before the tail kernel takes the paths still in flight (0.9^24 = 8 % of the rays of a sub-path lie beyond)
+#endif
+MI_DEV void step_store_surf(float4* q, const Surf& s) {
+  q[0] = make_float4(s.position.x, s.position.y, s.position.z, __uint_as_float(s.material_id));
+  q[1] = make_float4(s.gnormal.x, s.gnormal.y, s.gnormal.z, s.tangent.c0.x);
+  q[2] = make_float4(s.tangent.c0.y, s.tangent.c0.z, s.tangent.c1.x, s.tangent.c1.y);
+  q[3] = make_float4(s.tangent.c1.z, s.tangent.c2.x, s.tangent.c2.y, s.tangent.c2.z);
+}
+MI_DEV Surf step_load_surf(const float4* q) {
+  const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+  Surf s;
+  s.position = xyz(a); s.material_id = __float_as_uint(a.w);
+  s.gnormal = xyz(b);
+  s.tangent.c0 = F3(b.w, c.x, c.y); s.tangent.c1 = F3(c.z, c.w, d.x); s.tangent.c2 = F3(d.y, d.z, d.w);
+  return s;
+}
+template <bool ON> struct StepStack { TravStackT<true> s; };
+template <> struct StepStack<false> {};
+MI_DEV EVert lvert_as_evert(const LVert& t) { EVert x; x.surface = t.surface; x.omega = t.omega; x.throughput = t.throughput; x.c = t.a; x.C = t.A; x.finite = t.finite; return x; }
+MI_DEV LVert evert_as_lvert(const EVert& x) { LVert t; t.surface = x.surface; t.omega = x.omega; t.throughput = x.throughput; t.a = x.c; t.A = x.C; t.finite = x.finite; return t; }
+
+// in_slot < 0: the first round (every path of the launch starts); else the paths of step_active[in_slot] (step_count[in_slot] of them, read on the device: no
+// round waits for the host) resume.  INLINE (QN = node format): the tail — a resumed path walks its own rays here and runs to its end, nothing is appended.
+template <bool LIST, bool INLINE, int QN>
+__global__ __launch_bounds__(kBlock, INLINE ? 4 : MI_BPT_STEP_WAVES) void bpt_step(const RenderParams p, const BptState w, int in_slot, uint32_t out_slot) {
+  extern __shared__ float4 smem[];
+  StepStack<INLINE> stack_holder;  // only the tail walks rays itself: the rounds' kernel carries no traversal stack (its 512-byte spill array would be scratch)
+  void* stack_ptr = nullptr;
+  if constexpr (INLINE) {
+    stack_holder.s.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
+    stack_holder.s.cap = p.stack_entries;
+    stack_ptr = &stack_holder.s;
+  }
+  const uint32_t* __restrict__ active_in = in_slot < 0 ? nullptr : w.step_active[in_slot];
+  const uint32_t n_in = in_slot < 0 ? w.lanes : w.step_count[in_slot];
+  uint32_t n_overflow = 0;
+  for (uint32_t base = blockIdx.x * kBlock; base < n_in; base += gridDim.x * kBlock) {  // wave-uniform trip count: the ballots below see whole waves
+  const uint32_t j = base + threadIdx.x;
+  const bool have = j < n_in;
+  const uint32_t i = have ? (active_in ? active_in[j] : j) : 0u;
+  bool emit = false, overflow = false;
+  if (have) {
+    SceneView sv = p.sv;
+    Ctx c; ctx_init(c, p, w, stack_ptr, sv.blob, &sv);
+    c.flat_k = 0u; c.flat_k_mesh = 0u;
+    const Lane ln = lane_decode<LIST>(p, w, i);
+    float4* st = w.step_state + size_t(i) * kBptStepF4;
+    float4* lrec = w.lslab + size_t(i) * w.max_vertices * 7u;
+    float4* erec = w.eslab + size_t(i) * w.max_vertices * 7u;
+    float4* nrec = w.nslab + size_t(i) * w.max_vertices * 7u;
+    float4* em = w.emission + size_t(i) * w.max_vertices;
+    uint2* evi = w.evinfo + size_t(i) * w.max_vertices;
+    uint32_t phase = kStepStart, L = 0, E = 0, n_items = 0, n_em = 0, n_dir = 0, basic = 0, size = 0, prv = 0, k = 0;
+    bool at_camera = false;
+    Rng g; g.state = 0u;
+    LVert pv; Surf surface; BSample b;  // pv: the previous vertex of the sub-path being traced (an EVert's c / C ride in a / A: same record, one set of registers)
+    pv.surface.position = F3(0, 0, 0); pv.surface.gnormal = F3(0, 0, 0); pv.surface.tangent.c0 = pv.surface.tangent.c1 = pv.surface.tangent.c2 = F3(0, 0, 0);
+    pv.surface.material_id = 0u; pv.omega = F3(0, 0, 0); pv.throughput = F3(0, 0, 0); pv.a = pv.A = 0.0f; pv.finite = 1;
+    surface = pv.surface;
+    b.q = bq_zero(); b.omega = F3(0, 0, 0);
+    if (active_in) {
+      const uint4 s0 = reinterpret_cast<const uint4*>(st)[0], s1 = reinterpret_cast<const uint4*>(st)[1], s2 = reinterpret_cast<const uint4*>(st)[2];
+      phase = s0.x; g.state = s0.y; L = s0.z; E = s0.w;
+      n_items = s1.x; n_em = s1.y; n_dir = s1.z; basic = s1.w;
+      size = s2.x; prv = s2.y; k = s2.z; at_camera = (s2.w & 1u) != 0u;
+      pv = rec_load_l(st + 3);
+      const float4 b0 = st[14], b1 = st[15];
+      b.omega = xyz(b0); b.q.density = b0.w; b.q.throughput = xyz(b1); b.q.densityRev = b1.w; b.q.finite = (s2.w & 2u) ? 1 : 0;
+      // Scene::intersect's second half (Scene.cpp:198-202): the surface point of the hit the walk found for this path's ray
+      const float4 ro = w.step_rays[2 * size_t(i)], rd = w.step_rays[2 * size_t(i) + 1], hv = w.step_hits[i];
+      Hit h; h.t = hv.x; h.u = hv.y; h.v = hv.z; h.pos = __float_as_uint(hv.w); h.id = h.pos == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u; h.den = 1.0f;
+      // `surface` = what the path's ray found (material_id 0xFFFFFFFF: nothing); the surface the ray left from is not needed again
+      if (h.id == 0xFFFFFFFFu) { surface.material_id = 0xFFFFFFFFu; }
+      else surface = query_surface<8>(sv.blob, sv, xyz(ro), xyz(rd), h);
+    }
+    // the coroutine: pc names the point of bpt_trace the path continues at
+    enum { PC_START, PC_LIGHT_HEAD, PC_LIGHT_RESUME, PC_LIGHT_END, PC_EYE_START, PC_EYE_HEAD, PC_EYE_RESUME, PC_END, PC_SUSPEND };
+    int pc = phase == kStepStart ? PC_START : (phase == kStepLight ? PC_LIGHT_RESUME : PC_EYE_RESUME);
+    f3 ray_dir = F3(0, 0, 1), ray_pos = F3(0, 0, 0), ray_gn = F3(0, 0, 1); uint32_t ray_mask = 0xFFFFFFFFu;  // the ray about to leave: Scene::intersect(from, dir) with its mask
+    bool done = false;
+    while (!done) {
+      switch (pc) {
+        case PC_START: {
+          if (!ln.ok) { pc = PC_END; break; }
+          g = rng_seed(p.seed, ln.py * p.width + ln.px, ln.sample);
+          (void)rng_f(g); (void)rng_f(g);  // the camera sample's two uniforms (re-drawn at PC_EYE_START)
+          if (bpt_roulette(c, g)) { pc = PC_END; break; }  // BPT.cpp:17-19
+          if (bpt_roulette(c, g)) { pc = PC_EYE_START; break; }  // _traceLight (BPT.cpp:121-190) returns an empty sub-path
+          const LSample ls = light_sample(c, g);
+          pv = sample_to_vertex(c, ls);
+          size = 1; prv = 0;
+          pc = PC_LIGHT_HEAD;
+        } break;
+        case PC_LIGHT_HEAD: {
+          if (bpt_roulette(c, g)) { pc = PC_LIGHT_END; break; }
+          b = bpt_bsdf_sample(c, g, pv.surface, pv.omega);
+          ray_pos = pv.surface.position; ray_gn = pv.surface.gnormal; ray_dir = b.omega; ray_mask = 1u << MI_ENTITY_MESH;
+          phase = kStepLight; pc = PC_SUSPEND;
+        } break;
+        case PC_LIGHT_RESUME: {
+          if (surface.material_id == 0xFFFFFFFFu) { pc = PC_LIGHT_END; break; }
+          if (size >= w.max_vertices) { overflow = true; pc = PC_LIGHT_END; break; }
+          LVert cur;
+          cur.surface = surface;
+          cur.omega = -b.omega;
+          const Edge e = make_edge(pv.surface, cur.surface, cur.omega);
+          cur.throughput = ((pv.throughput * b.q.throughput) * e.bCos) * c.rinv;
+          if (l1norm(cur.throughput) < MI_FLT_EPSILON) { pc = PC_LIGHT_END; break; }
+          cur.throughput = cur.throughput / b.q.density;
+          pv.finite = pv.finite < b.q.finite ? pv.finite : b.q.finite;
+          cur.finite = b.q.finite;
+          cur.a = 1.0f / betaf(c, e.fG * b.q.density);
+          cur.A = (pv.A * betaf(c, b.q.densityRev) + pv.a * float(pv.finite)) * betaf(c, e.bG) * cur.a;
+          if (b.q.finite == 0) { pv = cur; }
+          else { rec_store_l(lrec + size_t(prv) * 7u, pv); pv = cur; prv = size; ++size; }
+          pc = PC_LIGHT_HEAD;
+        } break;
+        case PC_LIGHT_END: {
+          const BSample last = bpt_bsdf_sample(c, g, pv.surface, pv.omega);
+          if (last.q.finite == 0) --size; else rec_store_l(lrec + size_t(prv) * 7u, pv);
+          L = size;
+          pc = PC_EYE_START;
+        } break;
+        case PC_EYE_START: {
+          const m33 v2w = {F3(p.v2w[0], p.v2w[1], p.v2w[2]), F3(p.v2w[3], p.v2w[4], p.v2w[5]), F3(p.v2w[6], p.v2w[7], p.v2w[8])};
+          Surf cs;  // Technique::_camera_surface (Technique.cpp:107-116)
+          cs.position = F3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+          cs.tangent.c0 = v2w.c1; cs.tangent.c1 = -v2w.c2; cs.tangent.c2 = v2w.c0;
+          cs.material_id = (0u << 2) | MI_ENTITY_CAMERA;
+          cs.gnormal = -v2w.c2;
+          Rng g0 = rng_seed(p.seed, ln.py * p.width + ln.px, ln.sample);  // the camera ray of this sample (bpt_trace forms it before the light sub-path)
+          const float u0 = rng_f(g0), u1 = rng_f(g0);
+          const float fx = float(ln.px) + u0, fy = float(ln.py) + u1;
+          const float vx = fx * p.res_y_inv * 2.0f - p.res_x * p.res_y_inv;
+          const float vy = fy * p.res_y_inv * 2.0f - 1.0f;
+          const f3 dir = mulmv(v2w, normalize(F3(vx, vy, -p.focal_length_y)));
+          surface = cs;
+          pv.surface = surface; pv.omega = -dir; pv.throughput = F3(1, 1, 1) * c.rinv;
+          pv.finite = 1; pv.a = 0.0f; pv.A = 0.0f;
+          pc = PC_EYE_HEAD;
+        } break;
+        case PC_EYE_HEAD: {
+          at_camera = (pv.surface.material_id & 3u) == MI_ENTITY_CAMERA;
+          if (E >= w.max_vertices) { overflow = true; pc = PC_END; break; }
+          if (at_camera) {
+            rec_store_e(erec + size_t(E) * 7u, lvert_as_evert(pv), 0u, 0u);  // items [0, L): the splats of _connect_eye
+            evi[E] = make_uint2(0u, 0u);
+            n_items = L;
+          } else {
+            uint32_t kind = 0;
+            if (!bpt_roulette(c, g)) {  // BPT.cpp:278-288
+              const LSample nb = light_sample(c, g);
+              if (!nb.directional) { kind = 1; rec_store_l(nrec + size_t(E) * 7u, sample_to_vertex(c, nb)); }
+              else { kind = 2; rec_store_dir(nrec + size_t(E) * 7u, nb); ++n_dir; }
+            }
+            rec_store_e(erec + size_t(E) * 7u, lvert_as_evert(pv), kind, n_items);
+            evi[E] = make_uint2(kind, n_items);
+            n_items += (kind ? 1u : 0u) + (L > 1u ? L - 1u : 0u);
+          }
+          k = E;
+          ++E;
+          b = bpt_bsdf_sample(c, g, pv.surface, pv.omega);
+          ray_pos = surface.position; ray_gn = surface.gnormal; ray_dir = b.omega; ray_mask = 0xFFFFFFFFu;
+          phase = kStepEye; pc = PC_SUSPEND;
+        } break;
+        case PC_EYE_RESUME: {
+          if (surface.material_id == 0xFFFFFFFFu) {
+            if (at_camera) {  // BPT.cpp:49-51: a miss from the camera vertex returns the sky gradient instead of what was gathered through emitters
+              const f3 sky = (c.sky_horizon * (1 - b.omega.z) + c.sky_zenith * b.omega.z) * c.rinv;
+              em[0] = make_float4(sky.x, sky.y, sky.z, __uint_as_float(0u)); n_em = 1;
+            }
+            pc = PC_END; break;
+          }
+          EVert cur;
+          cur.surface = surface; cur.omega = -b.omega;
+          const Edge e = make_edge(pv.surface, cur.surface, cur.omega);
+          cur.throughput = (pv.throughput * b.q.throughput) * e.bCos;
+          if (l1norm(cur.throughput) < MI_FLT_EPSILON) { pc = PC_END; break; }
+          cur.throughput = cur.throughput / b.q.density;
+          pv.finite = pv.finite < b.q.finite ? pv.finite : b.q.finite;
+          cur.finite = b.q.finite;
+          cur.c = 1.0f / betaf(c, e.fG * b.q.density);
+          cur.C = (pv.A * betaf(c, b.q.densityRev) + pv.a * float(pv.finite)) * betaf(c, e.bG) * cur.c;
+          if (surf_is_light(surface)) {
+            const f3 t = bpt_connect_light(c, cur);
+            if (n_em >= w.max_vertices) { overflow = true; pc = PC_END; break; }
+            em[n_em++] = make_float4(t.x, t.y, t.z, __uint_as_float(k));
+            ray_pos = surface.position; ray_gn = surface.gnormal; ray_dir = b.omega; ray_mask = 0xFFFFFFFFu;  // through the emitter, same direction
+            phase = kStepEye; pc = PC_SUSPEND;
+          } else {
+            pv = evert_as_lvert(cur);
+            if (bpt_roulette(c, g)) { pc = PC_END; break; }
+            pv.throughput = pv.throughput * c.rinv;
+            pc = PC_EYE_HEAD;
+          }
+        } break;
+        case PC_END: {
+          w.info[2 * size_t(i)] = make_uint4(L, E, n_items, n_em);
+          w.info[2 * size_t(i) + 1] = make_uint4(basic, n_dir, (ln.py << 16) | ln.px, (ln.fl << 1) | (ln.ok ? 1u : 0u));
+          w.item_offset[i] = n_items;
+          done = true;
+        } break;
+        default: {  // PC_SUSPEND: Scene::intersect's first half (Scene.cpp:185-197) — the nudged origin; the walk and the surface query follow in the next round
+          if constexpr (INLINE) {  // the tail: the ray is walked here (scene_intersect as in bpt_trace) and the path goes on
+            Surf from; from.position = ray_pos; from.gnormal = ray_gn; from.tangent = surface.tangent; from.material_id = 0u;  // scene_intersect reads position and gnormal
+            surface = scene_intersect<QN>(c, from, ray_dir, ray_mask);
+            ++basic;
+            pc = phase == kStepLight ? PC_LIGHT_RESUME : PC_EYE_RESUME;
+            break;
+          }
+          const f3 org = nudge(ray_pos, ray_gn, ray_dir);
+          w.step_rays[2 * size_t(i)] = make_float4(org.x, org.y, org.z, __uint_as_float(ray_mask));
+          w.step_rays[2 * size_t(i) + 1] = make_float4(ray_dir.x, ray_dir.y, ray_dir.z, 0.0f);
+          ++basic;
+          reinterpret_cast<uint4*>(st)[0] = make_uint4(phase, g.state, L, E);
+          reinterpret_cast<uint4*>(st)[1] = make_uint4(n_items, n_em, n_dir, basic);
+          reinterpret_cast<uint4*>(st)[2] = make_uint4(size, prv, k, (at_camera ? 1u : 0u) | (b.q.finite ? 2u : 0u));
+          rec_store_l(st + 3, pv);
+          st[14] = make_float4(b.omega.x, b.omega.y, b.omega.z, b.q.density);
+          st[15] = make_float4(b.q.throughput.x, b.q.throughput.y, b.q.throughput.z, b.q.densityRev);
+          emit = true; done = true;
+        } break;
+      }
+    }
+  }
+  // the paths with a ray in flight, appended wave by wave
+  const uint64_t m = __ballot(emit);
+  if (m != 0ull) {
+    const uint32_t lane = threadIdx.x & 63u, leader = uint32_t(__ffsll((unsigned long long)m)) - 1u;
+    uint32_t at = 0;
+    if (lane == leader) at = atomicAdd(&w.step_count[out_slot], uint32_t(__popcll(m)));
+    at = __shfl(at, int(leader), 64);
+    if (emit) w.step_active[out_slot][at + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u))] = i;
+  }
+  n_overflow += uint32_t(__popcll(__ballot(overflow)));
+  }
+  if (n_overflow != 0u && (threadIdx.x & 63u) == 0u && p.counters) atomicAdd(&p.counters[15], (unsigned long long)n_overflow);
+}
+
+// the closest-hit walk of the rays in flight: one lane per ray, Scene::intersect's rtcIntersect (Scene.cpp:198) with the ray's geometry mask
+template <int QN>
+__global__ __launch_bounds__(kBlock, 6) void bpt_closest(const RenderParams p, const BptState w, uint32_t slot) {
+  extern __shared__ float4 smem[];
+  TravStackT<true> stack;
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
+  stack.cap = p.stack_entries;
+  const uint32_t* __restrict__ active = w.step_active[slot];
+  const uint32_t n = w.step_count[slot];
+  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+    const uint32_t i = active[j];
+    const float4 ro = w.step_rays[2 * size_t(i)], rd = w.step_rays[2 * size_t(i) + 1];
+    Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
+    traverse<false, false, QN, 4>(p.sv.blob, p.sv, stack, xyz(ro), xyz(rd), __float_as_uint(ro.w), h);
+    w.step_hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.id == 0xFFFFFFFFu ? 0xFFFFFFFFu : h.pos));
+  }
+}
+
 // exclusive scan of the per-path item counts (w.lanes + 1 entries, the last receives the total): tiles of 2048 entries are
 // scanned by one workgroup each, their totals by a single workgroup, then added back
 constexpr uint32_t kScanTile = 2048;
@@ -1127,6 +1404,59 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, grid, block, lds, stream, p, w);
+  {
+    const uint32_t total = w.lanes + 1u, tiles = (total + kScanTile - 1u) / kScanTile;
+    hipLaunchKernelGGL(bpt_scan_tiles, dim3(tiles), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);
+    hipLaunchKernelGGL(bpt_scan_sums, dim3(1), dim3(1024), 0, stream, w.scan_tmp, tiles);
+    hipLaunchKernelGGL(bpt_scan_add, dim3((total + 255u) / 256u), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);
+  }
+  e = hipMemcpyAsync(total_items, w.item_offset + w.lanes, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+// stage A as uniform steps: MI_BPT_STEP_ROUNDS rounds of (bpt_closest, bpt_step) — the list of paths in flight and its count stay on the device, no round waits
+// for the host, the grids shrink with the expected survivors and stride over whatever the count turns out to be — then the tail kernel (paths still in flight
+// walk their remaining rays themselves), then the scan of the item counts
+hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool list, hipStream_t stream, uint32_t* total_items, uint32_t* rounds) {
+  hipError_t e = hipMemsetAsync(w.item_offset + w.lanes, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(w.step_count, 0, 2 * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  const bool wide = p.wide_nodes == 1u;
+  void (*step)(const RenderParams, const BptState, int, uint32_t) = list ? bpt_step<true, false, 1> : bpt_step<false, false, 1>;
+  void (*tail)(const RenderParams, const BptState, int, uint32_t) = list ? (wide ? bpt_step<true, true, 2> : bpt_step<true, true, 1>) : (wide ? bpt_step<false, true, 2> : bpt_step<false, true, 1>);
+  void (*walk)(const RenderParams, const BptState, uint32_t) = wide ? bpt_closest<2> : bpt_closest<1>;
+  const size_t lds = size_t(p.stack_entries) * kBlock * 4;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(walk), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  if (e != hipSuccess) return e;
+  const uint32_t all_blocks = (w.lanes + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(step, dim3(all_blocks), dim3(kBlock), 0, stream, p, w, -1, 0u);
+  uint32_t slot = 0;
+  int n_rounds = MI_BPT_STEP_ROUNDS;
+  if (const char* r = std::getenv("MI_BPT_STEP_ROUNDS")) { const int v = std::atoi(r); if (v >= 0 && v <= 4096) n_rounds = v; }
+  double expect = 1.0;  // upper estimate of the share of the launch's paths still in flight: a sub-path survives a round with probability < roulette
+  for (int r = 0; r < n_rounds; ++r) {
+    uint32_t blocks = uint32_t(double(all_blocks) * expect * 1.25) + 64u;
+    if (blocks > all_blocks) blocks = all_blocks;
+    e = hipMemsetAsync(w.step_count + (slot ^ 1u), 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(walk, dim3(blocks), dim3(kBlock), lds, stream, p, w, slot);
+    hipLaunchKernelGGL(step, dim3(blocks), dim3(kBlock), 0, stream, p, w, int(slot), slot ^ 1u);
+    slot ^= 1u;
+    const double q = p.roulette < 0.98f ? double(p.roulette) * 1.02 : 1.0;  // a path is in flight while either of its two sub-paths is: P(sum of two lengths > r)
+    expect = q >= 1.0 ? 1.0 : std::min(1.0, (1.0 + (1.0 - q) * double(r + 1)) * std::pow(q, double(r + 1)) * 1.5);
+  }
+  {  // the paths still in flight have a ray waiting: one more walk, then they run to their ends in the tail kernel (which walks its further rays itself)
+    uint32_t blocks = uint32_t(double(all_blocks) * expect * 1.25) + 64u;
+    if (blocks > all_blocks) blocks = all_blocks;
+    hipLaunchKernelGGL(walk, dim3(blocks), dim3(kBlock), lds, stream, p, w, slot);
+    hipLaunchKernelGGL(tail, dim3(blocks), dim3(kBlock), lds, stream, p, w, int(slot), slot ^ 1u);
+  }
+  if (rounds) *rounds = uint32_t(n_rounds);
   {
     const uint32_t total = w.lanes + 1u, tiles = (total + kScanTile - 1u) / kScanTile;
     hipLaunchKernelGGL(bpt_scan_tiles, dim3(tiles), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);

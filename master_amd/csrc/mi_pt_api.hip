@@ -70,6 +70,7 @@ struct mi_pt_handle {
   float* bpt_eye = nullptr; size_t bpt_eye_bytes = 0;
   double* bpt_light = nullptr; size_t bpt_light_bytes = 0;
   float sphere[4] = {0, 0, 0, 0};
+  uint32_t bpt_step_rounds = 0;  // rounds of the last BPT launch's tracing stage as uniform steps (0: the per-lane form ran)
   float sky_horizon[3] = {0, 0, 0}, sky_zenith[3] = {0, 0, 0};
   // frames in flight (mi_pt_render_frames_async / mi_pt_render_async / mi_pt_wait): a batch = the frames of ONE launch; per batch slot the
   // frames' device framebuffers (contiguous), their pinned host copies, counters, partial sums and a stream of its own
@@ -1281,7 +1282,12 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
   const bool lds = use_lds_scene(h) && h->stack_fits_lds;  // small scenes with shallow trees: padded copy of the blob in LDS, binary walk, stack without a spill path
   auto run = [&](mi::BptState& ws, bool* overflow) -> int {
     uint32_t total = 0;
-    HIP_TRY(bl.trace(p, ws, list, lds, stream, &total));
+    // r04: scenes read from HBM trace their sub-paths as uniform steps (bpt_step / bpt_closest rounds, bpt_kernels.hip) instead of one lane walking both
+    // sub-paths of its path; MI_BPT_STEPS=0/1 forces the per-lane form / the steps (the kernels of LDS-resident scenes always walk per lane)
+    bool steps = false;  // measured (profiles/r04/ab_bpt_steps.txt): not yet ahead of the per-lane form — opt-in
+    if (const char* e = std::getenv("MI_BPT_STEPS")) steps = std::atoi(e) != 0 && !lds && ws.step_state != nullptr;
+    if (steps) { uint32_t rounds = 0; HIP_TRY(bl.trace_steps(p, ws, list, stream, &total, &rounds)); h->bpt_step_rounds = rounds; }
+    else { HIP_TRY(bl.trace(p, ws, list, lds, stream, &total)); h->bpt_step_rounds = 0; }
     unsigned long long over = 0;
     HIP_TRY(hipMemcpy(&over, h->d_counters + 15, sizeof over, hipMemcpyDeviceToHost));
     if (over) { *overflow = true; HIP_TRY(hipMemsetAsync(h->d_counters + 15, 0, sizeof over, stream)); return MI_OK; }
@@ -1349,12 +1355,16 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   std::memcpy(w.sky_horizon, h->sky_horizon, sizeof w.sky_horizon); std::memcpy(w.sky_zenith, h->sky_zenith, sizeof w.sky_zenith);
   if (width > 65535u || height > 65535u)  // the staged form packs a path's pixel as (y << 16) | x in its info record (bpt_kernels.hip)
     return fail(MI_ERR_UNSUPPORTED, "BPT: width and height must not exceed 65535");
-  uint64_t lanes = total_lanes < (1ull << 20) ? total_lanes : (1ull << 20);  // up to 1 M paths per launch
+  uint64_t max_lanes = 1ull << 20;  // up to 1 M paths per launch (MI_BPT_LANES_LOG2 = 16 .. 22: measurement)
+  if (const char* e = std::getenv("MI_BPT_LANES_LOG2")) { const int v = std::atoi(e); if (v >= 16 && v <= 22) max_lanes = 1ull << v; }
+  uint64_t lanes = total_lanes < max_lanes ? total_lanes : max_lanes;
   lanes = (lanes + 255) / 256 * 256;
   const bool staged = bpt_staged();
-  // vertex slabs: at most 3 x 16 GB (staged) or 24 GB, and at most 40 % of what the device has free right now (another process may share
+  // vertex slabs: at most 3 x 36 GB (staged) or 24 GB, and at most 40 % of what the device has free right now (another process may share
   // the GPU; a smaller GPU has less): the capacity per sub-path shrinks, long paths then go through the slice path of bpt_launch
-  uint64_t budget = staged ? (16ull << 30) : (24ull << 30);
+  // r04: 3 x 36 GB — a launch of 1 M paths (several frames) keeps 320 vertices per sub-path: with fewer, a sub-path outgrows its share every few launches at
+  // roulette 0.9 (P(length > 146) = 2e-7 per sub-path, two million sub-paths per launch) and the launch is redone in slices; the device has 288 GB
+  uint64_t budget = staged ? (36ull << 30) : (24ull << 30);
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
@@ -1371,7 +1381,8 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     w.max_vertices = uint32_t(cap);
     if (staged) {
       const size_t slab = size_t(lanes) * cap * 112;
-      const size_t need = 3 * slab + size_t(lanes) * (cap * 24 + 32 + 4 + 1) + 8192;
+      const size_t step_bytes = size_t(lanes) * (mi::kBptStepF4 * 16 + 32 + 16 + 8) + 4096;  // tracing stage as uniform steps: state, ray, hit, two index lists per path
+      const size_t need = 3 * slab + size_t(lanes) * (cap * 24 + 32 + 4 + 1) + 8192 + step_bytes;
       rc = ensure(reinterpret_cast<void**>(&h->bpt_arena), &h->bpt_arena_bytes, need);
       if (rc == MI_OK) {
         char* a = h->bpt_arena;
@@ -1382,6 +1393,12 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
         w.info = reinterpret_cast<uint4*>(take(size_t(lanes) * 32));
         w.item_offset = reinterpret_cast<uint32_t*>(take((size_t(lanes) + 1) * 4));
         w.scan_tmp = reinterpret_cast<uint32_t*>(take((size_t(lanes) / 2048 + 2) * 4));
+        w.step_state = reinterpret_cast<float4*>(take(size_t(lanes) * mi::kBptStepF4 * 16));
+        w.step_rays = reinterpret_cast<float4*>(take(size_t(lanes) * 32));
+        w.step_hits = reinterpret_cast<float4*>(take(size_t(lanes) * 16));
+        w.step_active[0] = reinterpret_cast<uint32_t*>(take(size_t(lanes) * 4));
+        w.step_active[1] = reinterpret_cast<uint32_t*>(take(size_t(lanes) * 4));
+        w.step_count = reinterpret_cast<uint32_t*>(take(256));
       }
     } else {
       rc = ensure(reinterpret_cast<void**>(&h->bpt_slab), &h->bpt_slab_bytes, size_t(lanes) * cap * 112);
@@ -1417,7 +1434,9 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
   HIP_TRY(hipSetDevice(h->device));
   mi::RenderParams p; mi::BptState w; uint32_t per_launch = 0;
   const uint64_t tiles_x = (uint64_t(win.w) + 7) / 8, tiles_y = (uint64_t(win.h) + 7) / 8, total = tiles_x * tiles_y * 64;
-  int rc = bpt_prepare(h, camera_id, width, height, total, p, w, &per_launch);
+  // lanes of a launch: up to 1 M paths over SEVERAL frames (r04: a launch of one 512 x 512 frame is 4 096 waves — one round of the chip, which then waits for
+  // its longest sub-path; with four frames per launch that tail overlaps the next waves' work)
+  int rc = bpt_prepare(h, camera_id, width, height, total * uint64_t(spp), p, w, &per_launch);
   if (rc) return rc;
   p.win_x0 = win.x0; p.win_y0 = win.y0; p.win_w = win.w; p.win_h = win.h; p.tiles_x = uint32_t(tiles_x); p.tiles_y = uint32_t(tiles_y);
   p.spp = spp; p.seed = seed; p.sample_offset = sample_offset; p.n_chunks = 1;

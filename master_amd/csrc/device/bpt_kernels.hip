@@ -883,21 +883,144 @@ __global__ __launch_bounds__(kBlock, INLINE ? 4 : MI_BPT_STEP_WAVES) void bpt_st
   if (n_overflow != 0u && (threadIdx.x & 63u) == 0u && p.counters) atomicAdd(&p.counters[15], (unsigned long long)n_overflow);
 }
 
-// the closest-hit walk of the rays in flight: one lane per ray, Scene::intersect's rtcIntersect (Scene.cpp:198) with the ray's geometry mask
+// The closest-hit walk of the rays in flight — Scene::intersect's rtcIntersect (Scene.cpp:198) with the ray's geometry mask — by PERSISTENT waves: a lane that
+// has finished its ray takes the next unstarted one of the list (chunks of kStepChunk rays from interleaved cursors, refill whenever `th` lanes idle), like the
+// any-hit walk of bpt_visibility.  Of a ray only (t, position) of the best hit live in the loop; U, V, |den| are formed again for the winner (the leaf's own
+// expressions on the same operands: the same bits as tri_test + finish_hit, as in traverse_dyn).
+constexpr uint32_t kStepChunk = 128u, kStepCursors = 64u;
 template <int QN>
-__global__ __launch_bounds__(kBlock, 6) void bpt_closest(const RenderParams p, const BptState w, uint32_t slot) {
+__global__ __launch_bounds__(kBlock, 6) void bpt_closest(const RenderParams p, const BptState w, uint32_t slot, uint32_t n_cursors, uint32_t th) {
   extern __shared__ float4 smem[];
+  const SceneView& sv = p.sv;
   TravStackT<true> stack;
   stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
   stack.cap = p.stack_entries;
   const uint32_t* __restrict__ active = w.step_active[slot];
-  const uint32_t n = w.step_count[slot];
-  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-    const uint32_t i = active[j];
-    const float4 ro = w.step_rays[2 * size_t(i)], rd = w.step_rays[2 * size_t(i) + 1];
-    Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0;
-    traverse<false, false, QN, 4>(p.sv.blob, p.sv, stack, xyz(ro), xyz(rd), __float_as_uint(ro.w), h);
-    w.step_hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.id == 0xFFFFFFFFu ? 0xFFFFFFFFu : h.pos));
+  const uint32_t n_rays = w.step_count[slot];
+  const float4* tris = sv.blob + sv.off_tris;
+  const uint4* __restrict__ qn = sv.qnodes;
+  const uint4* __restrict__ q4 = sv.qnodes4;
+  const f3 glo = F3(sv.grid_lo[0], sv.grid_lo[1], sv.grid_lo[2]), gis = F3(sv.grid_inv_step[0], sv.grid_inv_step[1], sv.grid_inv_step[2]);
+  const uint32_t lane = threadIdx.x & 63u;
+  const int root = sv.n_nodes == 0 ? ~0 : 0;
+  uint32_t* cursors = w.step_count + 8u;  // [kStepCursors], zeroed by the host before the launch
+  const uint32_t group = blockIdx.x % n_cursors;
+  uint32_t next = 0, end = 0;
+  bool exhausted = false, walking = false;
+  uint32_t item = 0, ray_mask = 0, best_pos = 0xFFFFFFFFu;
+  float best_t = __builtin_inff();
+  f3 co = F3(0, 0, 0), cd = F3(0, 0, 1);
+  RayBox rb = make_raybox(co, F3(1, 1, 1));
+  int sp = 0, node = 0;
+  for (;;) {
+    const uint64_t busy = __ballot(walking);
+    const uint32_t n_idle = 64u - uint32_t(__popcll(busy));
+    if (!exhausted && (busy == 0ull || n_idle >= th)) {
+      if (next == end) {
+        uint32_t k = 0;
+        if (lane == 0u) k = atomicAdd(&cursors[group], 1u);
+        k = __shfl(k, 0, 64);
+        const uint64_t v = (uint64_t(k) * n_cursors + group) * kStepChunk;
+        if (v >= uint64_t(n_rays)) { exhausted = true; continue; }
+        next = uint32_t(v); end = n_rays - next < kStepChunk ? n_rays : next + kStepChunk;
+      }
+      const uint64_t idle = ~busy;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
+      const uint32_t avail = end - next, take = n_idle < avail ? n_idle : avail;
+      if (!walking && rank < take) {
+        item = active[next + rank];
+        const float4 a = w.step_rays[2 * size_t(item)], b = w.step_rays[2 * size_t(item) + 1];
+        co = xyz(a); cd = xyz(b); ray_mask = __float_as_uint(a.w);
+        rb = QN ? make_raybox((co - glo) * gis, cd * gis) : make_raybox(co, cd);
+        best_t = __builtin_inff(); best_pos = 0xFFFFFFFFu;
+        sp = 0; node = root; walking = true;
+      }
+      next += take;
+      continue;
+    }
+    if (busy == 0ull) break;
+    if (walking) {
+      bool pop = false;
+      if (node >= 0) {
+        if (QN == 2) {
+          float t[4]; int l[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint4 a = q4[4 * node + k];
+            float tn;
+            const bool hk = wide_child_test(a, rb, best_t, tn) && int(a.w) != kEmptyLink;
+            t[k] = hk ? tn : __builtin_inff();
+            l[k] = int(a.w);
+          }
+#define MI_CSWAP(a, b) do { const bool s_ = t[b] < t[a]; const float ta_ = s_ ? t[b] : t[a], tb_ = s_ ? t[a] : t[b]; \
+                            const int la_ = s_ ? l[b] : l[a], lb_ = s_ ? l[a] : l[b]; t[a] = ta_; t[b] = tb_; l[a] = la_; l[b] = lb_; } while (0)
+          MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); MI_CSWAP(1, 3); MI_CSWAP(1, 2);
+#undef MI_CSWAP
+          if (t[0] < __builtin_inff()) {
+            if (t[3] < __builtin_inff()) { stack.push(sp, uint32_t(l[3])); ++sp; }
+            if (t[2] < __builtin_inff()) { stack.push(sp, uint32_t(l[2])); ++sp; }
+            if (t[1] < __builtin_inff()) { stack.push(sp, uint32_t(l[1])); ++sp; }
+            node = l[0];
+          } else {
+            pop = true;
+          }
+        } else {
+          const uint4 a = qn[2 * node], b = qn[2 * node + 1];
+          const int l0 = int(a.w), l1 = int(b.w);
+          float tn0, tn1;
+          const bool h0 = wide_child_test(a, rb, best_t, tn0), h1 = wide_child_test(b, rb, best_t, tn1);
+          if (h0 && h1) {
+            const bool sw = tn1 < tn0;
+            stack.push(sp, uint32_t(sw ? l0 : l1));
+            ++sp;
+            node = sw ? l1 : l0;
+          } else if (h0 || h1) {
+            node = h0 ? l0 : l1;
+          } else {
+            pop = true;
+          }
+        }
+      } else {
+        // Embree single-ray Moeller-Trumbore (tri_test in pt_device.h), closest hit by (t, id)
+        const uint32_t pos = uint32_t(~node) & kLeafPosMask;  // bit 30 of ~node: pair leaf (layout.h), the triangle at pos + 1 is this lane's next iteration
+        const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
+        const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
+        const uint32_t id = __float_as_uint(c.y), gmask = __float_as_uint(c.z);
+        const f3 ng = cross(e2, e1);
+        const f3 C = v0 - co;
+        const f3 R = cross(C, cd);
+        const float den = dot(ng, cd);
+        const float absden = fabsf(den);
+        const float sgn = den < 0.0f ? -1.0f : 1.0f;
+        const float U = dot(R, e2) * sgn;
+        const float V = dot(R, e1) * sgn;
+        const float T = dot(ng, C) * sgn;
+        pop = true;
+        if ((gmask & ray_mask) != 0u && den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absden && absden * 0.0f < T) {
+          const float t = T / absden;
+          if (t < best_t || (t == best_t && (best_pos == 0xFFFFFFFFu || id < __float_as_uint(tris[3 * best_pos + 2].y)))) { best_t = t; best_pos = pos; }
+        }
+        if ((uint32_t(node) & kLeafPairBit) == 0u) { node = int((uint32_t(node) | kLeafPairBit) - 1u); pop = false; }  // ~(pos + 1), a single leaf
+      }
+      if (pop) {
+        if (sp == 0) {
+          // the ray is done: U, V, |den| of the winner (same expressions, same operands: same bits), then finish_hit's two divisions
+          float hu = 0.0f, hv = 0.0f;
+          if (best_pos != 0xFFFFFFFFu) {
+            const float4 a = tris[3 * best_pos], b = tris[3 * best_pos + 1], c = tris[3 * best_pos + 2];
+            const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
+            const f3 ng = cross(e2, e1);
+            const f3 R = cross(v0 - co, cd);
+            const float den = dot(ng, cd);
+            const float sgn = den < 0.0f ? -1.0f : 1.0f;
+            const float ad = fabsf(den);
+            hu = (dot(R, e2) * sgn) / ad; hv = (dot(R, e1) * sgn) / ad;
+          }
+          w.step_hits[item] = make_float4(best_t, hu, hv, __uint_as_float(best_pos));
+          walking = false;
+        } else { --sp; node = int(stack.pop(sp)); }
+      }
+    }
   }
 }
 
@@ -1427,8 +1550,20 @@ hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool 
   const bool wide = p.wide_nodes == 1u;
   void (*step)(const RenderParams, const BptState, int, uint32_t) = list ? bpt_step<true, false, 1> : bpt_step<false, false, 1>;
   void (*tail)(const RenderParams, const BptState, int, uint32_t) = list ? (wide ? bpt_step<true, true, 2> : bpt_step<true, true, 1>) : (wide ? bpt_step<false, true, 2> : bpt_step<false, true, 1>);
-  void (*walk)(const RenderParams, const BptState, uint32_t) = wide ? bpt_closest<2> : bpt_closest<1>;
   const size_t lds = size_t(p.stack_entries) * kBlock * 4;
+  void (*walk)(const RenderParams, const BptState, uint32_t, uint32_t, uint32_t) = wide ? bpt_closest<2> : bpt_closest<1>;
+  uint32_t walk_th = 16u;
+  if (const char* t = std::getenv("MI_BPT_STEP_TH")) { const int v = std::atoi(t); if (v >= 1 && v <= 64) walk_th = uint32_t(v); }
+  // persistent walkers: at most 8 workgroups per CU are resident; a launch for fewer rays than that brings fewer workgroups
+  auto launch_walk = [&](uint32_t slot_, double share) -> hipError_t {
+    hipError_t e2 = hipMemsetAsync(w.step_count + 8, 0, kStepCursors * sizeof(uint32_t), stream);
+    if (e2 != hipSuccess) return e2;
+    uint32_t want = uint32_t(double(w.lanes) * share / double(kStepChunk * kWavesPerBlock)) + 64u;
+    const uint32_t cap = 256u * 6u;
+    if (want > cap) want = cap;
+    hipLaunchKernelGGL(walk, dim3(want), dim3(kBlock), lds, stream, p, w, slot_, want < kStepCursors ? want : kStepCursors, walk_th);
+    return hipSuccess;
+  };
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(walk), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -1444,7 +1579,8 @@ hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool 
     if (blocks > all_blocks) blocks = all_blocks;
     e = hipMemsetAsync(w.step_count + (slot ^ 1u), 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(walk, dim3(blocks), dim3(kBlock), lds, stream, p, w, slot);
+    e = launch_walk(slot, expect);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(step, dim3(blocks), dim3(kBlock), 0, stream, p, w, int(slot), slot ^ 1u);
     slot ^= 1u;
     const double q = p.roulette < 0.98f ? double(p.roulette) * 1.02 : 1.0;  // a path is in flight while either of its two sub-paths is: P(sum of two lengths > r)
@@ -1453,7 +1589,8 @@ hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool 
   {  // the paths still in flight have a ray waiting: one more walk, then they run to their ends in the tail kernel (which walks its further rays itself)
     uint32_t blocks = uint32_t(double(all_blocks) * expect * 1.25) + 64u;
     if (blocks > all_blocks) blocks = all_blocks;
-    hipLaunchKernelGGL(walk, dim3(blocks), dim3(kBlock), lds, stream, p, w, slot);
+    e = launch_walk(slot, expect);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tail, dim3(blocks), dim3(kBlock), lds, stream, p, w, int(slot), slot ^ 1u);
   }
   if (rounds) *rounds = uint32_t(n_rounds);

@@ -1398,7 +1398,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
         w.step_hits = reinterpret_cast<float4*>(take(size_t(lanes) * 16));
         w.step_active[0] = reinterpret_cast<uint32_t*>(take(size_t(lanes) * 4));
         w.step_active[1] = reinterpret_cast<uint32_t*>(take(size_t(lanes) * 4));
-        w.step_count = reinterpret_cast<uint32_t*>(take(256));
+        w.step_count = reinterpret_cast<uint32_t*>(take(1024));  // [0..1] list counts, [8..71] chunk cursors of the walking waves
       }
     } else {
       rc = ensure(reinterpret_cast<void**>(&h->bpt_slab), &h->bpt_slab_bytes, size_t(lanes) * cap * 112);

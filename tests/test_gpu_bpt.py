@@ -156,6 +156,32 @@ def test_bpt_visibility_stage_is_bit_identical_per_path(monkeypatch, name, wide)
     assert pt.last_stats.num_shadow_rays > 0 or name == "TestCase10"
 
 
+@pytest.mark.parametrize("name,wide", [("LivingRoomLit", 1), ("CornellBoxSpecular", 1), ("MetalRings", 0), ("TestCase10", 1)])
+@pytest.mark.parametrize("rounds", ["0", "3", "60"])
+def test_bpt_tracing_stage_as_uniform_steps_is_bit_identical_per_path(monkeypatch, name, wide, rounds):
+    """r04: the tracing stage as uniform steps — a path is a coroutine suspended at every closest-hit ray; bpt_step resumes the paths that
+    have a hit waiting and runs them to their next ray, persistent waves with lane refill (bpt_closest) walk the rays of a round, and after
+    MI_BPT_STEP_ROUNDS rounds the tail kernel lets the paths still in flight run to their ends.  Same draws in the same order, same records: eye
+    radiance, splat sums and ray counts per path equal the per-lane form's (and with it the oracle's), whatever the number of rounds (none: every path
+    ends in the tail; 60: nearly every path ends in a round).  Measured slower than the per-lane form so far (profiles/r04/ab_bpt_steps.txt): opt-in."""
+    s = load_scene(name)
+    pt = ma.PathTracing(s, beta=2.0)
+    xy, si = _paths(64, 48, 12000, 17)
+    monkeypatch.setenv("MI_PT_WIDE_NODES", str(wide))
+    monkeypatch.setenv("MI_BPT_STEPS", "0")
+    a = pt.bpt_trace_paths(64, 48, xy, si, seed=6)
+    img_a = pt.bpt_render_rgbn(40, 30, spp=5, seed=2)
+    monkeypatch.setenv("MI_BPT_STEPS", "1"); monkeypatch.setenv("MI_BPT_STEP_ROUNDS", rounds)
+    b = pt.bpt_trace_paths(64, 48, xy, si, seed=6)
+    img_b = pt.bpt_render_rgbn(40, 30, spp=5, seed=2)
+    assert np.array_equal(a[2], b[2]) and _bits_equal(a[0], b[0]).all() and _bits_equal(a[1], b[1]).all()
+    assert np.array_equal(img_a[..., 3], img_b[..., 3])
+    np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)  # FP64 splat order is free
+    if rounds == "3" and name == "CornellBoxSpecular":  # and against the oracle directly
+        o = oracle.Oracle(s, beta=2.0).bpt_trace_paths(64, 48, xy[:3000], si[:3000], seed=6)
+        assert np.array_equal(np.asarray(b[2])[:3000], np.asarray(o[2])) and _bits_equal(b[0][:3000], o[0]).all() and _bits_equal(b[1][:3000], o[1]).all()
+
+
 def test_bpt_visibility_stage_against_the_oracle(monkeypatch):
     """the forced visibility stage against the CPU oracle directly (not only against the other device form)"""
     monkeypatch.setenv("MI_BPT_DYN_VIS", "1")

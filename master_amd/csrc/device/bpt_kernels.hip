@@ -1259,8 +1259,7 @@ __global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const
         const float T = dot(ng, C) * sgn;
         pop = true;
         if ((gmask & (1u << MI_ENTITY_MESH)) != 0u && den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absden && absden * 0.0f < T) {
-          const float t = T / absden;
-          if (t <= 1.0f) { w.occl[item] = 1u; walking = false; pop = false; }
+          if (T <= absden) { w.occl[item] = 1u; walking = false; pop = false; }  // t = T / |den| <= 1 <=> T <= |den| (pt_device.h tri_test): no division
         }
         if ((uint32_t(node) & kLeafPairBit) == 0u && walking) { node = int((uint32_t(node) | kLeafPairBit) - 1u); pop = false; }
       }

@@ -948,13 +948,13 @@ __global__ __launch_bounds__(kBlock, 6) void bpt_closest(const RenderParams p, c
           for (int k = 0; k < 4; ++k) {
             const uint4 a = q4[4 * node + k];
             float tn;
-            const bool hk = wide_child_test(a, rb, best_t, tn) && int(a.w) != kEmptyLink;
+            const bool hk = wide_child_test(a, rb, best_t, tn);
             t[k] = hk ? tn : __builtin_inff();
             l[k] = int(a.w);
           }
 #define MI_CSWAP(a, b) do { const bool s_ = t[b] < t[a]; const float ta_ = s_ ? t[b] : t[a], tb_ = s_ ? t[a] : t[b]; \
                             const int la_ = s_ ? l[b] : l[a], lb_ = s_ ? l[a] : l[b]; t[a] = ta_; t[b] = tb_; l[a] = la_; l[b] = lb_; } while (0)
-          MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); MI_CSWAP(1, 3); MI_CSWAP(1, 2);
+          MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); if (MI_WIDE_SORT_FULL) { MI_CSWAP(1, 3); MI_CSWAP(1, 2); }
 #undef MI_CSWAP
           if (t[0] < __builtin_inff()) {
             if (t[3] < __builtin_inff()) { stack.push(sp, uint32_t(l[3])); ++sp; }
@@ -1201,13 +1201,13 @@ __global__ __launch_bounds__(kBlock, MI_BPT_VIS_WAVES) void bpt_visibility(const
           for (int k = 0; k < 4; ++k) {
             const uint4 a = q4[4 * node + k];
             float tn;
-            const bool hk = wide_child_test(a, rb, 1.0f, tn) && int(a.w) != kEmptyLink;
+            const bool hk = wide_child_test(a, rb, 1.0f, tn);
             t[k] = hk ? tn : __builtin_inff();
             l[k] = int(a.w);
           }
 #define MI_CSWAP(a, b) do { const bool s_ = t[b] < t[a]; const float ta_ = s_ ? t[b] : t[a], tb_ = s_ ? t[a] : t[b]; \
                             const int la_ = s_ ? l[b] : l[a], lb_ = s_ ? l[a] : l[b]; t[a] = ta_; t[b] = tb_; l[a] = la_; l[b] = lb_; } while (0)
-          MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); MI_CSWAP(1, 3); MI_CSWAP(1, 2);
+          MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); if (MI_WIDE_SORT_FULL) { MI_CSWAP(1, 3); MI_CSWAP(1, 2); }
 #undef MI_CSWAP
           if (t[0] < __builtin_inff()) {
             if (t[3] < __builtin_inff()) { stack.push(sp, uint32_t(l[3])); ++sp; }

@@ -559,7 +559,10 @@ __global__ void k_collapse4(uint32_t n_nodes, const mi_bvh_node* __restrict__ no
   const bool even = (x + 1 < n_nodes ? flag_scan[x + 1] : flag_scan[n_nodes]) != me;  // exclusive scan: the flag is the difference
   if (!even) return;
   uint4 out[4];
-  for (int k = 0; k < 4; ++k) out[k] = make_uint4(0u, 0u, 0u, 0x7FFFFFFFu);  // empty: link kEmptyLink (the walks test the link)
+  // an unused slot (r04): a box nothing enters in practice — the single point at the far corner of the grid, which overhangs the scene box by two cells, half
+  // extent 0 — and, should a ray pass exactly through it, a link that is harmless to follow: the leaf of the triangle at position 0 (a second test of a
+  // triangle changes neither the (t, id) minimum nor an occlusion).  The walks no longer test every child's link against a sentinel (4 v_cmp + 4 s_and per visit).
+  for (int k = 0; k < 4; ++k) out[k] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, 0xFFFFFFFFu);
   const mi_bvh_node n = nodes[x];
   int k = 0;
   auto put = [&](const float* lo, const float* hi, int link) {

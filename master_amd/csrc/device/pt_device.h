@@ -159,7 +159,11 @@ MI_DEV bool wide_child_test(const uint4 a, const RayBox& rb, float tmax, float& 
 #define MI_STACK_SPILL 128
 #endif
 constexpr uint32_t kStackSpill = MI_STACK_SPILL;
-constexpr int kEmptyLink = 0x7FFFFFFF;  // unused child slot of a wide node
+// unused child slots of a wide node carry a box nothing enters and the link of leaf 0 (bvh_build.hip k_collapse4): no sentinel to test
+#ifndef MI_WIDE_SORT_FULL
+#define MI_WIDE_SORT_FULL 1  // 1: the four children fully sorted by entry distance; 0: the nearest first, the other three in the order of two pair swaps — two
+                            // compare-exchanges fewer per visit, measured +-0.3 % on five scenes (what the order loses in visits the network saves): profiles/r04/ab_hbm_walk.txt
+#endif
 // The LDS part is addressed through an address-space-3 pointer: with a generic pointer the compiler cannot prove the
 // target is LDS next to the private spill array and falls back to FLAT loads/stores with 64-bit address arithmetic
 // on the pop -> next-node critical path; this way push/pop are ds_write_b32 / ds_read_b32.
@@ -223,14 +227,15 @@ MI_DEV void traverse_raw(const float4* __restrict__ sb, const SceneView& sv, Sta
         for (int k = 0; k < 4; ++k) {
           const uint4 a = q4[4 * node + k];
           float tn;
-          const bool hk = wide_child_test<FAR>(a, rb, h.t, tn) && int(a.w) != kEmptyLink;
+          const bool hk = wide_child_test<FAR>(a, rb, h.t, tn);
           t[k] = hk ? tn : __builtin_inff();
           l[k] = int(a.w);
         }
         if (COUNT) { ++vis->nodes; if (vis->wave_iters && __builtin_amdgcn_mbcnt_hi(uint32_t(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(__ballot(1)), 0u)) == 0) atomicAdd(&vis->wave_iters[0], 1u); }
 #define MI_CSWAP(a, b) do { const bool s_ = t[b] < t[a]; const float ta_ = s_ ? t[b] : t[a], tb_ = s_ ? t[a] : t[b]; \
                             const int la_ = s_ ? l[b] : l[a], lb_ = s_ ? l[a] : l[b]; t[a] = ta_; t[b] = tb_; l[a] = la_; l[b] = lb_; } while (0)
-        MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); MI_CSWAP(1, 3); MI_CSWAP(1, 2);
+        MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2);  // t[0] is the nearest; t[1] and t[3] keep the order of their pairs
+        if (MI_WIDE_SORT_FULL) { MI_CSWAP(1, 3); MI_CSWAP(1, 2); }
 #undef MI_CSWAP
         if (t[0] < __builtin_inff()) {
           if (t[3] < __builtin_inff()) { stack.push(sp, uint32_t(l[3])); ++sp; }
@@ -399,13 +404,14 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
           for (int k = 0; k < 4; ++k) {
             const uint4 a = q4[4 * node + k];
             float tn;
-            const bool hk = wide_child_test(a, rb, tmax, tn) && int(a.w) != kEmptyLink;
+            const bool hk = wide_child_test(a, rb, tmax, tn);
             t[k] = hk ? tn : __builtin_inff();
             l[k] = int(a.w);
           }
 #define MI_CSWAP(a, b) do { const bool s_ = t[b] < t[a]; const float ta_ = s_ ? t[b] : t[a], tb_ = s_ ? t[a] : t[b]; \
                             const int la_ = s_ ? l[b] : l[a], lb_ = s_ ? l[a] : l[b]; t[a] = ta_; t[b] = tb_; l[a] = la_; l[b] = lb_; } while (0)
-          MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2); MI_CSWAP(1, 3); MI_CSWAP(1, 2);
+          MI_CSWAP(0, 1); MI_CSWAP(2, 3); MI_CSWAP(0, 2);  // t[0] is the nearest; the rest is pushed in the order two pair swaps leave (r04: -2 of 5 compare-exchanges)
+          if (MI_WIDE_SORT_FULL) { MI_CSWAP(1, 3); MI_CSWAP(1, 2); }
 #undef MI_CSWAP
           if (t[0] < __builtin_inff()) {
             if (t[3] < __builtin_inff()) { stack.push(sp, uint32_t(l[3])); ++sp; }

@@ -466,15 +466,34 @@ def test_tiny_trees_with_pair_leaves_against_the_oracle(monkeypatch, n):
 
 def test_rccl_reduce_through_the_c_abi_world_of_one(cornell):
     """the reduce of the per-GPU framebuffers as a call of the library (north_star: "RCCL reduce over xGMI"), for hosts that run one
-    process per GPU — mi_pt_reduce_unique_id / _init / _rgbn / _finalize dlopen librccl.so and run ncclAllReduce / ncclReduce(sum, f32, H*W*4) in
-    place on the device framebuffer of mi_pt_render_device (merge_exr, Options.cpp:1340-1409).  One GPU per box: the communicator has ONE rank here
-    (initialising it and reducing over it is legal and runs the real RCCL code path); the sum over one rank is the identity.  UNMEASURED across GPUs."""
-    import torch
+    process per GPU — mi_pt_reduce_unique_id / _init / _rgbn / _finalize dlopen the librccl beside the HIP runtime in use and run ncclAllReduce /
+    ncclReduce(sum, f32, H*W*4) in place on the device framebuffer of mi_pt_render_device (merge_exr, Options.cpp:1340-1409).  One GPU per box: the
+    communicator has ONE rank here (initialising it and reducing over it is legal and runs the real RCCL code path); the sum over one rank is the
+    identity.  UNMEASURED across GPUs.  The device buffers come from the HIP runtime the library itself runs on (ctypes), like a C host's would: a
+    framework with its own bundled ROCm stack in the same process is exactly what the loader steps around (mi_pt_api.hip rccl())."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")  # the already loaded runtime of libmi_pt.so
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]; hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipDeviceSynchronize.argtypes = []
+
+    def dev_alloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        return p
+
+    def download(p, shape):
+        out = np.empty(shape, np.float32)
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), p, out.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return out
 
     assert ma.reduce_available()
     pt = ma.PathTracing(cornell, max_path=5)
+    w, h = 96, 64
+    fb = dev_alloc(w * h * 16)
     with pytest.raises(ma.MiError) as e:  # no communicator yet
-        pt.reduce_rgbn(1, 8, 8)
+        pt.reduce_rgbn(fb.value, w, h)
     assert e.value.code == -1
     uid = ma.reduce_unique_id()
     assert len(uid) == ma.REDUCE_ID_BYTES and any(uid)
@@ -483,22 +502,23 @@ def test_rccl_reduce_through_the_c_abi_world_of_one(cornell):
     pt.reduce_init(uid, 0, 1)
     with pytest.raises(ma.MiError):
         pt.reduce_init(uid, 0, 1)  # one communicator per handle
-    w, h = 96, 64
-    fb = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    pt.render_device(fb.data_ptr(), w, h, spp=8, seed=3, stream=stream)
-    before = fb.clone()
-    pt.reduce_rgbn(fb.data_ptr(), w, h, root=-1, stream=stream)   # all-reduce on the caller's stream
-    pt.reduce_rgbn(fb.data_ptr(), w, h, root=0)                   # reduce to rank 0 on the handle's stream (synchronised)
-    torch.cuda.synchronize()
-    assert torch.equal(fb, before) and bool((fb[..., 3] == 8).all())
+    pt.render_device(fb.value, w, h, spp=8, seed=3)
+    before = download(fb, (h, w, 4))
+    assert np.array_equal(before, pt.render_rgbn(w, h, spp=8, seed=3))
+    pt.reduce_rgbn(fb.value, w, h, root=-1)   # all-reduce on the handle's stream (synchronised)
+    pt.reduce_rgbn(fb.value, w, h, root=0)    # reduce to rank 0
+    after = download(fb, (h, w, 4))
+    assert np.array_equal(after, before) and np.all(after[..., 3] == 8)
     with pytest.raises(ma.MiError):
-        pt.reduce_rgbn(fb.data_ptr(), w, h, root=1)  # root outside the communicator
+        pt.reduce_rgbn(fb.value, w, h, root=1)  # root outside the communicator
     # the C5 payload: 3840 x 2160 x 4 f32 = 126.6 MiB in one call
-    big = torch.ones((2160, 3840, 4), dtype=torch.float32, device="cuda")
-    pt.reduce_rgbn(big.data_ptr(), 3840, 2160)
-    assert bool((big == 1).all())
+    big = dev_alloc(3840 * 2160 * 16)
+    ones = np.ones((2160, 3840, 4), np.float32)
+    assert hip.hipMemcpy(big, ones.ctypes.data_as(C.c_void_p), ones.nbytes, 1) == 0  # hipMemcpyHostToDevice
+    pt.reduce_rgbn(big.value, 3840, 2160)
+    assert np.array_equal(download(big, (2160, 3840, 4)), ones)
     pt.reduce_finalize()
     pt.reduce_finalize()  # idempotent
     with pytest.raises(ma.MiError):
-        pt.reduce_rgbn(fb.data_ptr(), w, h)
+        pt.reduce_rgbn(fb.value, w, h)
+    hip.hipFree(fb); hip.hipFree(big)

@@ -493,8 +493,11 @@ MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, void* sta
 #ifndef MI_BPT_ITEMS_WAVES
 #define MI_BPT_ITEMS_WAVES 6  // tools/sessions/ab_bpt_stage_waves.sh, 512^2 x 32: items 3/4/5/6 waves = 53.9/56.6/54.4/55.4 ms (Cornell), 280/281/282/272 ms (LivingRoomLit);
 #endif                        // trace 3/4/5 waves = 61.4/56.6/62.4 and 303/281/286 ms
-template <bool LIST, int QN>
-__global__ __launch_bounds__(kBlock, MI_BPT_TRACE_WAVES) void bpt_trace(const RenderParams p, const BptState w) {
+// WAVES: the register budget (waves per SIMD).  r04, 1 M paths per launch: six waves (80 VGPRs) beat four (128) on the models whose walk is a chain of dependent
+// fetches from L2 / HBM (LivingRoomLit 219 -> 207 ms, MetalRings 84.6 -> 82 ms per 64 frames) and lose on small trees (CornellBoxSpecular 129 -> 136 ms): chosen by
+// the size of the scene (bpt_stage_trace)
+template <bool LIST, int QN, int WAVES = MI_BPT_TRACE_WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void bpt_trace(const RenderParams p, const BptState w) {
   extern __shared__ float4 smem[];
   SceneView sv = p.sv;
   const float4* sb = sv.blob;
@@ -1521,6 +1524,10 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
   if (e != hipSuccess) return e;
   void (*fn)(const RenderParams, const BptState) = nullptr;
   if (lds_scene) fn = list ? bpt_trace<true, 0> : bpt_trace<false, 0>;
+  else if (p.sv.n_tris >= 16384u) {  // walks bound by dependent fetches: occupancy before registers
+    if (p.wide_nodes == 1u) fn = list ? bpt_trace<true, 2, 6> : bpt_trace<false, 2, 6>;
+    else fn = list ? bpt_trace<true, 1, 6> : bpt_trace<false, 1, 6>;
+  }
   else if (p.wide_nodes == 1u) fn = list ? bpt_trace<true, 2> : bpt_trace<false, 2>;
   else fn = list ? bpt_trace<true, 1> : bpt_trace<false, 1>;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

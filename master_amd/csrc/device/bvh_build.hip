@@ -595,6 +595,72 @@ __global__ void k_collapse4(uint32_t n_nodes, const mi_bvh_node* __restrict__ no
   for (int k2 = 0; k2 < 4; ++k2) q4[4 * size_t(me) + k2] = out[k2];
 }
 
+// r04 — area-guided collapse (the usual way a BVH4 is made from a BVH2; the strict two-level collapse above stays selectable, MI_PT_COLLAPSE=levels): a record
+// starts as the two children of its BVH2 node and, while it has fewer than four and one of them is internal, replaces the internal child of LARGEST surface
+// area by that child's two children.  Large boxes are the ones rays enter most often: opening them inside the record saves the visit of a record of their
+// own (lab on real segments, tests/lab: -6 .. -10 % wide-record visits per ray against the two-level collapse).  Which BVH2 nodes head a record is no longer a
+// matter of depth parity, so they are marked top-down, one level of records per pass; wide_kids() is the one definition both passes use.
+__device__ __forceinline__ float box_area3(const float* lo, const float* hi) {
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+struct WideKids { float lo[4][3], hi[4][3]; int link[4]; int n; };
+__device__ __forceinline__ void wide_kids(const mi_bvh_node* __restrict__ nodes, uint32_t x, WideKids& w) {
+  const mi_bvh_node n = nodes[x];
+  for (int a = 0; a < 3; ++a) { w.lo[0][a] = n.lo0[a]; w.hi[0][a] = n.hi0[a]; w.lo[1][a] = n.lo1[a]; w.hi[1][a] = n.hi1[a]; }
+  w.link[0] = n.link0; w.link[1] = n.link1; w.n = 2;
+  while (w.n < 4) {
+    int best = -1; float best_area = -1.0f;
+    for (int k = 0; k < w.n; ++k)
+      if (w.link[k] >= 0) { const float a = box_area3(w.lo[k], w.hi[k]); if (a > best_area) { best_area = a; best = k; } }
+    if (best < 0) break;
+    const mi_bvh_node m = nodes[w.link[best]];
+    for (int a = 0; a < 3; ++a) { w.lo[best][a] = m.lo0[a]; w.hi[best][a] = m.hi0[a]; w.lo[w.n][a] = m.lo1[a]; w.hi[w.n][a] = m.hi1[a]; }
+    w.link[best] = m.link0; w.link[w.n] = m.link1; ++w.n;
+  }
+}
+// state: 0 = not (yet) the head of a record, p + 1 = head to be expanded by pass p, kHeadDone = head, children marked.  pending[x] = entries a walk can have on its stack
+// when it enters record x (every visit pushes at most its other children): the maximum over all records + 3 is the exact capacity the wide walk needs.
+constexpr uint32_t kHeadDone = 0x80000000u;
+__global__ void k_mark_heads(uint32_t n_nodes, const mi_bvh_node* __restrict__ nodes, uint32_t* __restrict__ state, uint32_t* __restrict__ pending, uint32_t* __restrict__ max_need,
+                             uint32_t pass) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n_nodes || state[x] != pass + 1u) return;  // heads found by pass p - 1 carry the tag p + 1: strictly one level of records per launch
+  WideKids w; wide_kids(nodes, x, w);
+  const uint32_t below = pending[x] + uint32_t(w.n - 1);
+  for (int k = 0; k < w.n; ++k) if (w.link[k] >= 0) { pending[w.link[k]] = below; state[w.link[k]] = pass + 2u; }
+  atomicMax(max_need, below);
+  state[x] = kHeadDone;
+}
+__global__ void k_heads_to_flags(uint32_t n_nodes, const uint32_t* __restrict__ state, uint32_t* __restrict__ flag) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < n_nodes) flag[x] = state[x] == kHeadDone ? 1u : 0u;
+}
+__global__ void k_collapse4_area(uint32_t n_nodes, const mi_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ flag_scan, uint4* __restrict__ q4,
+                                 float lx, float ly, float lz, float ix, float iy, float iz, uint32_t pad_cells) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n_nodes) return;
+  const uint32_t me = flag_scan[x];
+  if ((x + 1 < n_nodes ? flag_scan[x + 1] : flag_scan[n_nodes]) == me) return;  // exclusive scan: the flag is the difference
+  WideKids w; wide_kids(nodes, x, w);
+  const float glo[3] = {lx, ly, lz}, gis[3] = {ix, iy, iz};
+  for (int k = 0; k < 4; ++k) {
+    uint4 a = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, 0xFFFFFFFFu);  // unused slot: see k_collapse4
+    if (k < w.n) {
+      uint32_t c[3], e[3];
+      for (int k3 = 0; k3 < 3; ++k3) {
+        const uint32_t ql = q_lo(w.lo[k][k3], glo[k3], gis[k3]), qh = q_hi(w.hi[k][k3], glo[k3], gis[k3]);
+        c[k3] = (ql + qh) >> 1;
+        const uint32_t ext = (qh - c[k3] > c[k3] - ql ? qh - c[k3] : c[k3] - ql) + pad_cells;
+        e[k3] = ext > 65535u ? 65535u : ext;
+      }
+      a.x = c[0] | (c[1] << 16); a.y = c[2] | (e[0] << 16); a.z = e[1] | (e[2] << 16);
+      a.w = w.link[k] >= 0 ? flag_scan[w.link[k]] : uint32_t(w.link[k]);
+    }
+    q4[4 * size_t(me) + k] = a;
+  }
+}
+
 #define BUILD_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 }  // namespace
@@ -743,20 +809,41 @@ hipError_t ce_nodes(uint32_t n_nodes, const float4* nodes, float4* out, hipStrea
 }
 
 hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, uint4* qnodes4, const float lo[3], const float inv_step[3],
-                          uint32_t pad_cells, hipStream_t stream) {
+                          uint32_t pad_cells, uint32_t depth, bool area_collapse, uint32_t* wide_stack_need, hipStream_t stream) {
+  if (wide_stack_need) *wide_stack_need = 0;
   if (n_nodes == 0) return hipSuccess;
   uint32_t* flag = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&flag), sizeof(uint32_t) * (size_t(n_nodes) + 1 + size_t(n_nodes) / kScanTile + 8));
+  // flags + scan scratch | head state | pending entries | maximum
+  const size_t n_flag = size_t(n_nodes) + 1 + size_t(n_nodes) / kScanTile + 8;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&flag), sizeof(uint32_t) * (n_flag + 2 * size_t(n_nodes) + 8));
   if (e != hipSuccess) return e;
+  uint32_t* state = flag + n_flag, *pending = state + n_nodes, *max_need = pending + n_nodes;
   hipMemsetAsync(flag + n_nodes, 0, sizeof(uint32_t), stream);
-  hipLaunchKernelGGL(k_even_depth, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, flag);
-  scan_exclusive(flag, n_nodes + 1, flag + n_nodes + 1, stream);
-  hipLaunchKernelGGL(k_collapse4, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, flag, qnodes4, lo[0], lo[1], lo[2], inv_step[0],
-                     inv_step[1], inv_step[2], pad_cells);
-  e = hipStreamSynchronize(stream);
+  const dim3 grid((n_nodes + 255) / 256), block(256);
+  if (area_collapse) {
+    hipMemsetAsync(state, 0, sizeof(uint32_t) * (2 * size_t(n_nodes) + 8), stream);
+    const uint32_t one = 1u;
+    hipMemcpyAsync(state, &one, sizeof one, hipMemcpyHostToDevice, stream);  // the root heads the first record
+    for (uint32_t pass = 0; pass < depth + 1u; ++pass)  // a record covers at least one BVH2 level: `depth` passes reach every head
+      hipLaunchKernelGGL(k_mark_heads, grid, block, 0, stream, n_nodes, nodes, state, pending, max_need, pass);
+    hipLaunchKernelGGL(k_heads_to_flags, grid, block, 0, stream, n_nodes, state, flag);
+    scan_exclusive(flag, n_nodes + 1, flag + n_nodes + 1, stream);
+    hipLaunchKernelGGL(k_collapse4_area, grid, block, 0, stream, n_nodes, nodes, flag, qnodes4, lo[0], lo[1], lo[2], inv_step[0], inv_step[1], inv_step[2], pad_cells);
+    uint32_t need = 0;
+    e = hipMemcpyAsync(&need, max_need, sizeof need, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (wide_stack_need) *wide_stack_need = need;
+  } else {
+    hipLaunchKernelGGL(k_even_depth, grid, block, 0, stream, n_nodes, nodes, flag);
+    scan_exclusive(flag, n_nodes + 1, flag + n_nodes + 1, stream);
+    hipLaunchKernelGGL(k_collapse4, grid, block, 0, stream, n_nodes, nodes, flag, qnodes4, lo[0], lo[1], lo[2], inv_step[0],
+                       inv_step[1], inv_step[2], pad_cells);
+    e = hipStreamSynchronize(stream);
+    if (wide_stack_need) *wide_stack_need = 3u * ((depth > 1 ? depth - 1u : 1u) + 1u) / 2u;  // up to three children pending per two binary levels
+  }
   hipFree(flag);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_quantize, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, n_nodes, nodes, qnodes, lo[0], lo[1], lo[2], inv_step[0],
+  hipLaunchKernelGGL(k_quantize, grid, block, 0, stream, n_nodes, nodes, qnodes, lo[0], lo[1], lo[2], inv_step[0],
                      inv_step[1], inv_step[2], pad_cells);
   return hipGetLastError();
 }

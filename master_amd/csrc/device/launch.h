@@ -13,8 +13,10 @@ hipError_t build_bvh(int builder, uint32_t nt, const float* pos, const float* ta
                      float scene_lo[3], float scene_hi[3], uint32_t* max_depth_out, float* build_ms, uint32_t* rounds_out, int2* plain_links, bool pairs,
                      hipStream_t stream);
 
+// pad_cells: padding of every quantised child box in grid cells (1; more for cameras far outside the grid).  area_collapse: wide records by the area-guided
+// collapse (r04) instead of two BVH2 levels per record; wide_stack_need (host): the stack entries the wide walk can need at most
 hipError_t quantize_nodes(uint32_t n_nodes, const mi_bvh_node* nodes, uint4* qnodes, uint4* qnodes4, const float lo[3], const float inv_step[3],
-                          uint32_t pad_cells, hipStream_t stream);  // pad_cells: padding of every quantised child box in grid cells (1; more for cameras far outside the grid)
+                          uint32_t pad_cells, uint32_t depth, bool area_collapse, uint32_t* wide_stack_need, hipStream_t stream);
 
 hipError_t ce_nodes(uint32_t n_nodes, const float4* nodes, float4* out, hipStream_t stream);  // centre / half-extent copy of the full-precision nodes
 

@@ -399,7 +399,11 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     uint32_t pad_cells = 1u + uint32_t(std::min(far_cells * 0x1p-20, 60000.0));
     if (const char* e = std::getenv("MI_PT_QUANT_PAD")) { const int v = std::atoi(e); if (v >= 1 && v <= 60000) pad_cells = uint32_t(v); }  // tests: shows what the guard prevents
     h->quant_pad_cells = pad_cells;
-    HIP_TRY(mi::quantize_nodes(n_nodes, reinterpret_cast<const mi_bvh_node*>(h->blob + sv.off_nodes), h->qnodes, h->qnodes4, h->sv.grid_lo, h->sv.grid_inv_step, pad_cells, h->stream));
+    bool area_collapse = true;  // MI_PT_COLLAPSE=levels: two BVH2 levels per wide record (rounds 1-3; A/B)
+    if (const char* e = std::getenv("MI_PT_COLLAPSE")) area_collapse = std::strcmp(e, "levels") != 0;
+    uint32_t wide_need = 0;
+    HIP_TRY(mi::quantize_nodes(n_nodes, reinterpret_cast<const mi_bvh_node*>(h->blob + sv.off_nodes), h->qnodes, h->qnodes4, h->sv.grid_lo, h->sv.grid_inv_step, pad_cells, depth,
+                               area_collapse, &wide_need, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->sv.qnodes = h->qnodes; h->sv.qnodes4 = h->qnodes4;
     {  // absolute padding of centre / half-extent boxes (pt_device.h ce_box_test, traverse_flat): rays start within the scene box or at a camera
@@ -471,7 +475,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     // LDS part of the stack: at most 12 entries (12 KB per workgroup); deeper levels spill to private memory
     uint32_t se = need < 12u ? need : 12u;
     // the wide walk of the HBM-resident kernels leaves up to three children pending per two binary levels
-    uint32_t need4 = 3u * ((depth > 1 ? depth - 1u : 1u) + 1u) / 2u;
+    uint32_t need4 = wide_need;  // exact for the area-guided collapse (k_mark_heads), the two-levels bound otherwise
     need4 = (need4 + 3u) / 4u * 4u;
     if (need4 < need) need4 = need;
     uint32_t lds_rows = 12u;  // LDS rows of the traversal stack (1 KB each per workgroup); deeper levels live in private memory

@@ -53,6 +53,7 @@ struct BptState {
   hipError_t bpt_launch_frame(const RenderParams& p, const BptState& w, bool list, hipStream_t stream);                                            \
   hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, bool lds_scene, hipStream_t stream, uint32_t* total_items);      \
   hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool list, hipStream_t stream, uint32_t* total_items, uint32_t* rounds); \
+  hipError_t bpt_stage_trace_passes(const RenderParams& p, const BptState& w, bool list, hipStream_t stream, uint32_t* total_items, uint32_t* rounds); \
   hipError_t bpt_stage_connect(const RenderParams& p, const BptState& w, bool list, bool lds_scene, uint32_t total_items, hipStream_t stream);     \
   hipError_t bpt_launch_commit(const RenderParams& p, const BptState& w, hipStream_t stream);                                                      \
   }
@@ -65,15 +66,16 @@ struct BptLaunchers {
   hipError_t (*frame)(const RenderParams&, const BptState&, bool, hipStream_t);
   hipError_t (*trace)(const RenderParams&, const BptState&, bool, bool, hipStream_t, uint32_t*);
   hipError_t (*trace_steps)(const RenderParams&, const BptState&, bool, hipStream_t, uint32_t*, uint32_t*);
+  hipError_t (*trace_passes)(const RenderParams&, const BptState&, bool, hipStream_t, uint32_t*, uint32_t*);
   hipError_t (*connect)(const RenderParams&, const BptState&, bool, bool, uint32_t, hipStream_t);
   hipError_t (*commit)(const RenderParams&, const BptState&, hipStream_t);
 };
 // the set compiled for `features` (RenderParams::features, kFeat* bits; for BPT kFeatPow means beta not in {0, 1, 2})
 inline BptLaunchers bpt_launchers(uint32_t features) {
   features &= 7u;  // the BPT kernels are not specialised on the number of lights
-  if (features == 0u) return {bpt_plain::bpt_launch_frame, bpt_plain::bpt_stage_trace, bpt_plain::bpt_stage_trace_steps, bpt_plain::bpt_stage_connect, bpt_plain::bpt_launch_commit};
-  if ((features & 4u) == 0u) return {bpt_fixed::bpt_launch_frame, bpt_fixed::bpt_stage_trace, bpt_fixed::bpt_stage_trace_steps, bpt_fixed::bpt_stage_connect, bpt_fixed::bpt_launch_commit};
-  return {bpt_all::bpt_launch_frame, bpt_all::bpt_stage_trace, bpt_all::bpt_stage_trace_steps, bpt_all::bpt_stage_connect, bpt_all::bpt_launch_commit};
+  if (features == 0u) return {bpt_plain::bpt_launch_frame, bpt_plain::bpt_stage_trace, bpt_plain::bpt_stage_trace_steps, bpt_plain::bpt_stage_trace_passes, bpt_plain::bpt_stage_connect, bpt_plain::bpt_launch_commit};
+  if ((features & 4u) == 0u) return {bpt_fixed::bpt_launch_frame, bpt_fixed::bpt_stage_trace, bpt_fixed::bpt_stage_trace_steps, bpt_fixed::bpt_stage_trace_passes, bpt_fixed::bpt_stage_connect, bpt_fixed::bpt_launch_commit};
+  return {bpt_all::bpt_launch_frame, bpt_all::bpt_stage_trace, bpt_all::bpt_stage_trace_steps, bpt_all::bpt_stage_trace_passes, bpt_all::bpt_stage_connect, bpt_all::bpt_launch_commit};
 }
 
 }  // namespace mi

@@ -671,7 +671,11 @@ MI_DEV LVert evert_as_lvert(const EVert& x) { LVert t; t.surface = x.surface; t.
 // in_slot < 0: the first round (every path of the launch starts); else the paths of step_active[in_slot] (step_count[in_slot] of them, read on the device: no
 // round waits for the host) resume.  INLINE (QN = node format): the tail — a resumed path walks its own rays here and runs to its end, nothing is appended.
 template <bool LIST, bool INLINE, int QN>
-__global__ __launch_bounds__(kBlock, INLINE ? 4 : MI_BPT_STEP_WAVES) void bpt_step(const RenderParams p, const BptState w, int in_slot, uint32_t out_slot) {
+// budget (INLINE only; 0 = none): a path that has walked this many rays in this launch is suspended like in the rounds' kernel — its ray saved UNWALKED — and
+// continues in the next pass (pending_unwalked = 1 there: the resumed path walks that ray first).  Passes with growing budgets bound the time a wave waits for
+// its longest path while the survivors of a pass are packed into full waves again (bpt_stage_trace_passes).
+__global__ __launch_bounds__(kBlock, INLINE ? 4 : MI_BPT_STEP_WAVES) void bpt_step(const RenderParams p, const BptState w, int in_slot, uint32_t out_slot, uint32_t budget,
+                                                                                   uint32_t pending_unwalked) {
   extern __shared__ float4 smem[];
   StepStack<INLINE> stack_holder;  // only the tail walks rays itself: the rounds' kernel carries no traversal stack (its 512-byte spill array would be scratch)
   void* stack_ptr = nullptr;
@@ -716,8 +720,16 @@ __global__ __launch_bounds__(kBlock, INLINE ? 4 : MI_BPT_STEP_WAVES) void bpt_st
       const float4 b0 = st[14], b1 = st[15];
       b.omega = xyz(b0); b.q.density = b0.w; b.q.throughput = xyz(b1); b.q.densityRev = b1.w; b.q.finite = (s2.w & 2u) ? 1 : 0;
       // Scene::intersect's second half (Scene.cpp:198-202): the surface point of the hit the walk found for this path's ray
-      const float4 ro = w.step_rays[2 * size_t(i)], rd = w.step_rays[2 * size_t(i) + 1], hv = w.step_hits[i];
-      Hit h; h.t = hv.x; h.u = hv.y; h.v = hv.z; h.pos = __float_as_uint(hv.w); h.id = h.pos == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u; h.den = 1.0f;
+      const float4 ro = w.step_rays[2 * size_t(i)], rd = w.step_rays[2 * size_t(i) + 1];
+      Hit h; h.t = __builtin_inff(); h.u = h.v = 0.0f; h.id = 0xFFFFFFFFu; h.pos = 0; h.den = 1.0f;
+      bool walked = false;
+      if constexpr (INLINE) {
+        if (pending_unwalked) {  // the ray a budgeted pass left behind: rtcIntersect of Scene::intersect (Scene.cpp:198) with its mask, as scene_intersect does
+          traverse<false, false, QN, 4>(sv.blob, sv, stack_holder.s, xyz(ro), xyz(rd), __float_as_uint(ro.w), h);
+          walked = true;
+        }
+      }
+      if (!walked) { const float4 hv = w.step_hits[i]; h.t = hv.x; h.u = hv.y; h.v = hv.z; h.pos = __float_as_uint(hv.w); h.id = h.pos == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u; }
       // `surface` = what the path's ray found (material_id 0xFFFFFFFF: nothing); the surface the ray left from is not needed again
       if (h.id == 0xFFFFFFFFu) { surface.material_id = 0xFFFFFFFFu; }
       else surface = query_surface<8>(sv.blob, sv, xyz(ro), xyz(rd), h);
@@ -727,6 +739,7 @@ __global__ __launch_bounds__(kBlock, INLINE ? 4 : MI_BPT_STEP_WAVES) void bpt_st
     int pc = phase == kStepStart ? PC_START : (phase == kStepLight ? PC_LIGHT_RESUME : PC_EYE_RESUME);
     f3 ray_dir = F3(0, 0, 1), ray_pos = F3(0, 0, 0), ray_gn = F3(0, 0, 1); uint32_t ray_mask = 0xFFFFFFFFu;  // the ray about to leave: Scene::intersect(from, dir) with its mask
     bool done = false;
+    uint32_t rays_here = 0;  // rays this path has walked in this launch (INLINE with a budget)
     while (!done) {
       switch (pc) {
         case PC_START: {
@@ -850,9 +863,12 @@ __global__ __launch_bounds__(kBlock, INLINE ? 4 : MI_BPT_STEP_WAVES) void bpt_st
           done = true;
         } break;
         default: {  // PC_SUSPEND: Scene::intersect's first half (Scene.cpp:185-197) — the nudged origin; the walk and the surface query follow in the next round
-          if constexpr (INLINE) {  // the tail: the ray is walked here (scene_intersect as in bpt_trace) and the path goes on
+          bool walk_here = INLINE;
+          if constexpr (INLINE) { if (budget != 0u && rays_here >= budget) walk_here = false; }
+          if (walk_here) {  // the ray is walked here (scene_intersect as in bpt_trace) and the path goes on
+            ++rays_here;
             Surf from; from.position = ray_pos; from.gnormal = ray_gn; from.tangent = surface.tangent; from.material_id = 0u;  // scene_intersect reads position and gnormal
-            surface = scene_intersect<QN>(c, from, ray_dir, ray_mask);
+            if constexpr (INLINE) surface = scene_intersect<QN>(c, from, ray_dir, ray_mask);
             ++basic;
             pc = phase == kStepLight ? PC_LIGHT_RESUME : PC_EYE_RESUME;
             break;
@@ -1554,8 +1570,8 @@ hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool 
   e = hipMemsetAsync(w.step_count, 0, 2 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   const bool wide = p.wide_nodes == 1u;
-  void (*step)(const RenderParams, const BptState, int, uint32_t) = list ? bpt_step<true, false, 1> : bpt_step<false, false, 1>;
-  void (*tail)(const RenderParams, const BptState, int, uint32_t) = list ? (wide ? bpt_step<true, true, 2> : bpt_step<true, true, 1>) : (wide ? bpt_step<false, true, 2> : bpt_step<false, true, 1>);
+  void (*step)(const RenderParams, const BptState, int, uint32_t, uint32_t, uint32_t) = list ? bpt_step<true, false, 1> : bpt_step<false, false, 1>;
+  void (*tail)(const RenderParams, const BptState, int, uint32_t, uint32_t, uint32_t) = list ? (wide ? bpt_step<true, true, 2> : bpt_step<true, true, 1>) : (wide ? bpt_step<false, true, 2> : bpt_step<false, true, 1>);
   const size_t lds = size_t(p.stack_entries) * kBlock * 4;
   void (*walk)(const RenderParams, const BptState, uint32_t, uint32_t, uint32_t) = wide ? bpt_closest<2> : bpt_closest<1>;
   uint32_t walk_th = 16u;
@@ -1575,7 +1591,7 @@ hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool 
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;
   const uint32_t all_blocks = (w.lanes + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(step, dim3(all_blocks), dim3(kBlock), 0, stream, p, w, -1, 0u);
+  hipLaunchKernelGGL(step, dim3(all_blocks), dim3(kBlock), 0, stream, p, w, -1, 0u, 0u, 0u);
   uint32_t slot = 0;
   int n_rounds = MI_BPT_STEP_ROUNDS;
   if (const char* r = std::getenv("MI_BPT_STEP_ROUNDS")) { const int v = std::atoi(r); if (v >= 0 && v <= 4096) n_rounds = v; }
@@ -1587,7 +1603,7 @@ hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool 
     if (e != hipSuccess) return e;
     e = launch_walk(slot, expect);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(step, dim3(blocks), dim3(kBlock), 0, stream, p, w, int(slot), slot ^ 1u);
+    hipLaunchKernelGGL(step, dim3(blocks), dim3(kBlock), 0, stream, p, w, int(slot), slot ^ 1u, 0u, 0u);
     slot ^= 1u;
     const double q = p.roulette < 0.98f ? double(p.roulette) * 1.02 : 1.0;  // a path is in flight while either of its two sub-paths is: P(sum of two lengths > r)
     expect = q >= 1.0 ? 1.0 : std::min(1.0, (1.0 + (1.0 - q) * double(r + 1)) * std::pow(q, double(r + 1)) * 1.5);
@@ -1597,9 +1613,59 @@ hipError_t bpt_stage_trace_steps(const RenderParams& p, const BptState& w, bool 
     if (blocks > all_blocks) blocks = all_blocks;
     e = launch_walk(slot, expect);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tail, dim3(blocks), dim3(kBlock), lds, stream, p, w, int(slot), slot ^ 1u);
+    hipLaunchKernelGGL(tail, dim3(blocks), dim3(kBlock), lds, stream, p, w, int(slot), slot ^ 1u, 0u, 0u);
   }
   if (rounds) *rounds = uint32_t(n_rounds);
+  {
+    const uint32_t total = w.lanes + 1u, tiles = (total + kScanTile - 1u) / kScanTile;
+    hipLaunchKernelGGL(bpt_scan_tiles, dim3(tiles), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);
+    hipLaunchKernelGGL(bpt_scan_sums, dim3(1), dim3(1024), 0, stream, w.scan_tmp, tiles);
+    hipLaunchKernelGGL(bpt_scan_add, dim3((total + 255u) / 256u), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);
+  }
+  e = hipMemcpyAsync(total_items, w.item_offset + w.lanes, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+// stage A as PASSES with growing ray budgets (MI_BPT_STEPS=2): every path walks its own rays (the tail kernel's form) but is suspended after `budget` rays of a
+// pass; the survivors of a pass are packed into full waves for the next one, so a wave waits for at most `budget` rays instead of its longest path.
+hipError_t bpt_stage_trace_passes(const RenderParams& p, const BptState& w, bool list, hipStream_t stream, uint32_t* total_items, uint32_t* rounds) {
+  hipError_t e = hipMemsetAsync(w.item_offset + w.lanes, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(w.step_count, 0, 2 * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  const bool wide = p.wide_nodes == 1u;
+  void (*pass)(const RenderParams, const BptState, int, uint32_t, uint32_t, uint32_t) = list ? (wide ? bpt_step<true, true, 2> : bpt_step<true, true, 1>) : (wide ? bpt_step<false, true, 2> : bpt_step<false, true, 1>);
+  const size_t lds = size_t(p.stack_entries) * kBlock * 4;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(pass), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  if (e != hipSuccess) return e;
+  uint32_t caps[8] = {10u, 20u, 40u, 80u, 0u, 0u, 0u, 0u}; int n_caps = 5;
+  if (const char* c = std::getenv("MI_BPT_PASS_CAPS")) {  // "12,24,48": budgets of the passes; a last pass without a budget is always added
+    n_caps = 0;
+    for (const char* q = c; *q && n_caps < 7;) { caps[n_caps++] = uint32_t(std::strtoul(q, nullptr, 10)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+    caps[n_caps++] = 0u;
+  }
+  const uint32_t all_blocks = (w.lanes + kBlock - 1) / kBlock;
+  uint32_t slot = 0;
+  double expect = 1.0;
+  for (int k = 0; k < n_caps; ++k) {
+    uint32_t blocks = uint32_t(double(all_blocks) * expect * 1.5) + 64u;
+    if (blocks < all_blocks / 8u) blocks = all_blocks / 8u;  // the estimate compounds optimistically over several passes; a small grid strides serially over what is left
+    if (blocks > all_blocks) blocks = all_blocks;
+    if (k == 0) {
+      hipLaunchKernelGGL(pass, dim3(all_blocks), dim3(kBlock), lds, stream, p, w, -1, 0u, caps[0], 0u);
+    } else {
+      e = hipMemsetAsync(w.step_count + (slot ^ 1u), 0, sizeof(uint32_t), stream);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(pass, dim3(blocks), dim3(kBlock), lds, stream, p, w, int(slot), slot ^ 1u, caps[k], 1u);
+      slot ^= 1u;
+    }
+    if (caps[k] == 0u) break;
+    const double q = p.roulette < 0.98f ? double(p.roulette) * 1.02 : 1.0;  // P(a path has more than `cap` rays left) <= (1 + (1 - q) cap) q^cap
+    expect = q >= 1.0 ? 1.0 : std::min(1.0, expect * (1.0 + (1.0 - q) * double(caps[k])) * std::pow(q, double(caps[k])) * 1.5);
+  }
+  if (rounds) *rounds = uint32_t(n_caps);
   {
     const uint32_t total = w.lanes + 1u, tiles = (total + kScanTile - 1u) / kScanTile;
     hipLaunchKernelGGL(bpt_scan_tiles, dim3(tiles), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);

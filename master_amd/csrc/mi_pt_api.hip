@@ -1290,7 +1290,10 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
     // sub-paths of its path; MI_BPT_STEPS=0/1 forces the per-lane form / the steps (the kernels of LDS-resident scenes always walk per lane)
     bool steps = false;  // measured (profiles/r04/ab_bpt_steps.txt): not yet ahead of the per-lane form — opt-in
     if (const char* e = std::getenv("MI_BPT_STEPS")) steps = std::atoi(e) != 0 && !lds && ws.step_state != nullptr;
-    if (steps) { uint32_t rounds = 0; HIP_TRY(bl.trace_steps(p, ws, list, stream, &total, &rounds)); h->bpt_step_rounds = rounds; }
+    int steps_mode = 1;  // MI_BPT_STEPS=1: rounds of (persistent walk, step) + tail; 2: passes with growing ray budgets, every path walking its own rays
+    if (const char* e = std::getenv("MI_BPT_STEPS")) steps_mode = std::atoi(e);
+    if (steps && steps_mode == 2) { uint32_t rounds = 0; HIP_TRY(bl.trace_passes(p, ws, list, stream, &total, &rounds)); h->bpt_step_rounds = rounds; }
+    else if (steps) { uint32_t rounds = 0; HIP_TRY(bl.trace_steps(p, ws, list, stream, &total, &rounds)); h->bpt_step_rounds = rounds; }
     else { HIP_TRY(bl.trace(p, ws, list, lds, stream, &total)); h->bpt_step_rounds = 0; }
     unsigned long long over = 0;
     HIP_TRY(hipMemcpy(&over, h->d_counters + 15, sizeof over, hipMemcpyDeviceToHost));

@@ -177,6 +177,10 @@ def test_bpt_tracing_stage_as_uniform_steps_is_bit_identical_per_path(monkeypatc
     assert np.array_equal(a[2], b[2]) and _bits_equal(a[0], b[0]).all() and _bits_equal(a[1], b[1]).all()
     assert np.array_equal(img_a[..., 3], img_b[..., 3])
     np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)  # FP64 splat order is free
+    # the same coroutine as PASSES with growing ray budgets (MI_BPT_STEPS=2): every path walks its own rays but is suspended after `budget` rays of a pass
+    monkeypatch.setenv("MI_BPT_STEPS", "2"); monkeypatch.setenv("MI_BPT_PASS_CAPS", {"0": "3", "3": "2,5,11", "60": "40"}[rounds])
+    c = pt.bpt_trace_paths(64, 48, xy, si, seed=6)
+    assert np.array_equal(a[2], c[2]) and _bits_equal(a[0], c[0]).all() and _bits_equal(a[1], c[1]).all()
     if rounds == "3" and name == "CornellBoxSpecular":  # and against the oracle directly
         o = oracle.Oracle(s, beta=2.0).bpt_trace_paths(64, 48, xy[:3000], si[:3000], seed=6)
         assert np.array_equal(np.asarray(b[2])[:3000], np.asarray(o[2])) and _bits_equal(b[0][:3000], o[0]).all() and _bits_equal(b[1][:3000], o[1]).all()

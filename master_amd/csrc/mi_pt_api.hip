@@ -479,6 +479,11 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
     need4 = (need4 + 3u) / 4u * 4u;
     if (need4 < need) need4 = need;
     uint32_t lds_rows = 12u;  // LDS rows of the traversal stack (1 KB each per workgroup); deeper levels live in private memory
+    {  // r04: a scene whose tables (materials, lights) push a workgroup of the dynamic-fetch kernels past a sixth of a CU's LDS with twelve rows keeps eight: six
+       // workgroups per CU instead of five (LivingRoomLit, 65 materials: 3 100 -> 3 177 Msamples/s; deeper stack levels live in private memory either way)
+      const size_t tables = size_t(sv.blob_f4 - sv.off_mats) * 16, rest = 7424 + 6464 + tables, share = (160u * 1024u) / 6u;
+      if (12u * 1024u + rest > share && 8u * 1024u + rest <= share) lds_rows = 8u;
+    }
     if (const char* e = std::getenv("MI_PT_STACK_ROWS")) { const int v = std::atoi(e); if (v >= 4 && v <= 12) lds_rows = uint32_t(v) / 4u * 4u; }
     const uint32_t se4 = need4 < lds_rows ? need4 : lds_rows;
     if (need4 > se4 + 128u) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack (12 LDS + 128 spill entries)");

@@ -485,6 +485,9 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
       if (12u * 1024u + rest > share && 8u * 1024u + rest <= share) lds_rows = 8u;
     }
     if (const char* e = std::getenv("MI_PT_STACK_ROWS")) { const int v = std::atoi(e); if (v >= 4 && v <= 12) lds_rows = uint32_t(v) / 4u * 4u; }
+    // a tree so lopsided that the wide walk could overrun the stack (LDS rows + 128 private entries) is walked through its binary records, whose need is the depth
+    bool wide_fits = true;
+    if (need4 > (need4 < lds_rows ? need4 : lds_rows) + 128u) { wide_fits = false; need4 = need; }
     const uint32_t se4 = need4 < lds_rows ? need4 : lds_rows;
     if (need4 > se4 + 128u) return fail(MI_ERR_UNSUPPORTED, "BVH depth " + std::to_string(depth) + " exceeds the traversal stack (12 LDS + 128 spill entries)");
     h->info.stack_entries = se;
@@ -517,6 +520,7 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
       if (!coarse) h->wide_nodes = true;
       if (const char* e = std::getenv("MI_PT_WIDE_NODES")) { h->wide_nodes = h->wide_large = std::atoi(e) != 0; if (h->wide_nodes) h->float_nodes = false; else h->float_nodes = coarse; }
       if (const char* e = std::getenv("MI_PT_FLOAT_NODES")) h->float_nodes = std::atoi(e) != 0;
+      if (!wide_fits) { h->wide_nodes = false; h->wide_large = false; if (!h->float_nodes) h->float_nodes = coarse; }  // no override re-enables a walk that can overrun its stack
     }
   }
   // scene bounding sphere for the emitters' bounded cosine sampling (BPT): the loader's value, or compute_bounding_sphere

@@ -583,3 +583,48 @@ def test_camera_far_outside_a_thin_scene_on_the_quantised_walks(monkeypatch, wid
     og, ogc = old.trace_paths(64, 48, xy, si, seed=13)
     lost = int((ogc[:, 0] != oc[:, 0]).sum())
     print("paths whose ray count changes with the one-cell padding: %d of %d" % (lost, len(oc)))
+
+
+def test_nested_shells_deep_unbalanced_tree_on_the_wide_walk(monkeypatch):
+    """r04: the wide records come from an area-guided collapse of the BVH2 (a record opens its child of largest area), so a record may span one to three BVH2
+    levels and the stack capacity of the wide walk is the exact maximum found by the marking pass, not a depth formula.  A scene built to be deep and lopsided —
+    sixty concentric octahedral shells, each 0.8 of the previous, with rays starting between the shells — walked through both node formats against the oracle."""
+    rng = np.random.default_rng(4)
+    b = sb.Builder()
+    b.add_camera((0, -3, 0.2), (0, 1, 0))
+    m = b.add_material(sb.material(ma.BSDF_DIFFUSE, diffuse=(0.6, 0.6, 0.6)))
+    v = np.array([(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)], np.float64)
+    faces = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    tris = []
+    for k in range(60):
+        r = 2.0 * 0.8 ** k
+        for f in faces:
+            if (k + f[0]) % 7 != 0:  # holes, so that rays thread several shells
+                tris.append([v[i] * r + rng.normal(scale=1e-3 * r, size=3) for i in f])
+    b.add_mesh(tris, m)
+    b.add_light((0, 0, 2.6), (0, 0, -1), (0, 1, 0), (0.8, 0.8), (20, 20, 20))
+    s = b.build()
+    orc = oracle.Oracle(s)
+    n = 20000
+    o = np.zeros(n, ma.SURFACE_DTYPE)
+    rad = 2.0 * 0.8 ** rng.uniform(0, 58, n)
+    dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    o["position"] = (dirs * rad[:, None] * 0.7).astype(np.float32)
+    o["gnormal"] = dirs.astype(np.float32)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True); d = d.astype(np.float32)
+    oh, ot, op = orc.intersect(o, d)
+    assert (op != 0xFFFFFFFF).mean() > 0.5
+    t = np.zeros(n, ma.SURFACE_DTYPE)
+    t["position"] = (rng.normal(size=(n, 3)) * 0.5).astype(np.float32); t["gnormal"] = d
+    ov = orc.occluded(o, t)
+    xy, si = grid_paths(32, 24, 6)
+    orr, oc = orc.trace_paths(32, 24, xy, si, seed=8)
+    for wide in ("1", "0"):
+        monkeypatch.setenv("MI_PT_WIDE_NODES", wide); monkeypatch.setenv("MI_PT_FLOAT_NODES", "0")
+        pt = ma.PathTracing(s)
+        assert pt.get_kernel() == ma.KERNEL_MEGA_GLOBAL and pt.bvh_info().max_depth >= 16
+        gh, gt, gp = pt.intersect(o, d)
+        assert np.array_equal(gp, op) and np.array_equal(gt, ot) and gh.tobytes() == oh.tobytes()
+        assert np.array_equal(pt.occluded(o, t), ov)
+        gr, gc = pt.trace_paths(32, 24, xy, si, seed=8)
+        assert np.array_equal(gc, oc) and np.array_equal(gr.view(np.uint32), orr.view(np.uint32))

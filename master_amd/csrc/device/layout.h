@@ -41,6 +41,8 @@ struct SceneView {
   const float4* ce_nodes;
   float grid_lo[3];
   float grid_inv_step[3];  // cells per world unit
+  uint32_t dyn_uni;        // traverse_dyn: 1 = one fetch per loop iteration whatever the lane is at (node or triangle record into the same registers), 0 = a load in each of
+                           // the two branches.  Measured (profiles/r04/ab_hbm_walk.txt): +3.5..6 % where the node records fit the L2 of an XCD (4 MB), -3..-10 % where they do not
   float box_pad;           // 2^-20 of the largest |coordinate| of the scene box and the cameras: absolute padding of centre / half-extent boxes (LDS node copy, flat leaf table)
 };
 

@@ -33,6 +33,7 @@ MI_DEV bool surf_is_light(const Surf& s) { return (s.material_id & 3u) == MI_ENT
 MI_DEV f3 to_world(const Surf& s, f3 v) { return mulmv(s.tangent, v); }
 MI_DEV f3 to_surface(const Surf& s, f3 v) { return mulvm(v, s.tangent); }
 MI_DEV f3 xyz(float4 v) { return F3(v.x, v.y, v.z); }
+MI_DEV float4 as_f4(uint4 v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
 
 // ---------------------------------------------------------------------------------------------
 // Ray / triangle: Embree 2 single-ray Moeller–Trumbore (rtcIntersect / rtcOccluded at
@@ -334,7 +335,7 @@ MI_DEV void dyn_park_shadow_ray(const DynLds& d, uint32_t lane, f3 org, f3 dir) 
 #define MI_DYN_STAT(k) do { } while (0)
 #endif
 // COUNT (instrumented variant): per-lane node / triangle visits by ray kind (whoever walks the ray) and the loop trips of the wave
-template <int QUANT, int NS, int TH, bool COUNT = false, class Stack>
+template <int QUANT, int NS, int TH, bool COUNT = false, bool UNI_T = false, class Stack>
 MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, Stack& stack, const DynLds& d, uint32_t lane, bool alive, f3 org, f3 dir, bool pend, Hit& h,
                           Visits* vis_c = nullptr, Visits* vis_s = nullptr, uint32_t* wave_trips = nullptr
 #ifdef MI_DYN_STATS
@@ -396,13 +397,25 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
     if (mode != 0u) {
       bool pop = false;
       const float tmax = mode == 2u ? 1.0f : h.t;
+      // r04 — ONE fetch per iteration whatever the lane is at.  An iteration of a wave nearly always has lanes at nodes AND lanes at leaves (75 % of them, r02
+      // census), and the two branches below are serialised: with a load in each, the wave paid two dependent memory latencies per iteration.  Now every lane
+      // reads ITS record before the branch — the 64-byte wide (or f32 binary) node, or the 48-byte triangle at the leaf — into the same sixteen registers, and the branches only compute.  (r02 requested BOTH record sets per lane and
+      // lost 9-45 % to the registers; here the two kinds share one set.)  UNI: scenes read from HBM through 64-byte records.
+      constexpr bool UNI = UNI_T && NS == 4 && (QUANT == 2 || QUANT == 0);  // a kernel variant of its own (as a run-time flag the two forms in one loop halved the throughput)
+      uint4 u0 = make_uint4(0u, 0u, 0u, 0u), u1 = u0, u2 = u0, u3 = u0;
+      if (UNI) {
+        const uint4* __restrict__ rec = node >= 0 ? (QUANT == 2 ? q4 + 4 * node : reinterpret_cast<const uint4*>(nodes + 4 * node))
+                                                   : reinterpret_cast<const uint4*>(tris + 3 * (uint32_t(~node) & kLeafPosMask));
+        u0 = rec[0]; u1 = rec[1]; u2 = rec[2];
+        if (node >= 0) u3 = rec[3];  // a triangle is 48 bytes: its lanes sit this load out (the 2 M-triangle scene is bound by 128-byte requests: -10 % with 64 bytes per triangle)
+      }
       if (node >= 0) {
         if (QUANT == 2) {
           // wide quantised node: the (up to) four grandchildren, nearest first, the others pushed farthest first (traverse() above)
           float t[4]; int l[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const uint4 a = q4[4 * node + k];
+            const uint4 a = UNI ? (k == 0 ? u0 : k == 1 ? u1 : k == 2 ? u2 : u3) : q4[4 * node + k];
             float tn;
             const bool hk = wide_child_test(a, rb, tmax, tn);
             t[k] = hk ? tn : __builtin_inff();
@@ -431,7 +444,8 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
             h0 = wide_child_test(a, rb, tmax, tn0);
             h1 = wide_child_test(b, rb, tmax, tn1);
           } else {
-            const float4 n0 = nodes[NS * node], n1 = nodes[NS * node + 1], n2 = nodes[NS * node + 2], n3 = nodes[NS * node + 3];
+            const float4 n0 = UNI ? as_f4(u0) : nodes[NS * node], n1 = UNI ? as_f4(u1) : nodes[NS * node + 1], n2 = UNI ? as_f4(u2) : nodes[NS * node + 2],
+                         n3 = UNI ? as_f4(u3) : nodes[NS * node + 3];
             l0 = __float_as_int(n0.w); l1 = __float_as_int(n1.w);
             h0 = ce_box_test<NS == 4>(xyz(n0), xyz(n1), rb, tmax, tn0); h1 = ce_box_test<NS == 4>(xyz(n2), xyz(n3), rb, tmax, tn1);  // LDS copy or sv.ce_nodes
           }
@@ -452,7 +466,7 @@ MI_DEV float traverse_dyn(const float4* __restrict__ sb, const SceneView& sv, St
         const uint32_t pos = uint32_t(~node) & kLeafPosMask;  // bit 30 of ~node: pair leaf, the triangle at pos + 1 is this lane's next iteration
         f3 co = org, cd = dir;
         if (mode == 2u) { co = F3(d.ray[owner], d.ray[64 + owner], d.ray[128 + owner]); cd = F3(d.ray[192 + owner], d.ray[256 + owner], d.ray[320 + owner]); }
-        const float4 a = tris[3 * pos], b = tris[3 * pos + 1], c = tris[3 * pos + 2];
+        const float4 a = UNI ? as_f4(u0) : tris[3 * pos], b = UNI ? as_f4(u1) : tris[3 * pos + 1], c = UNI ? as_f4(u2) : tris[3 * pos + 2];
         const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c.x);
         const uint32_t id = __float_as_uint(c.y), gmask = __float_as_uint(c.z);
         const f3 ng = cross(e2, e1);

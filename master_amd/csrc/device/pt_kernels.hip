@@ -95,7 +95,8 @@ constexpr uint32_t kAccBytesPerWave = 3 * 64 * 8 + 64 * 4 + 32;  // r, g, b sums
 // DYN: closest-hit and shadow rays of a trip share one traversal loop with dynamic fetch (traverse_dyn, pt_device.h);
 // the shadow ray of vertex k is resolved at the start of trip k + 1.
 // FLAT: the flat leaf list instead of the tree walk (traverse_flat, pt_device.h): no nodes in LDS, no traversal stack.
-template <bool LDS_SCENE, int MODE, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true, bool TBL = false, bool DYN = false, bool FLAT = false>
+// UNI (DYN, wide records read from HBM): one fetch per iteration of the unified loop whatever the lane is at (traverse_dyn)
+template <bool LDS_SCENE, int MODE, bool COUNT, int WAVES, int QN, int FEAT = kFeatAll, bool SPILL = true, bool TBL = false, bool DYN = false, bool FLAT = false, bool UNI = false>
 __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParams p) {
   constexpr bool LIST = MODE == 1, FRAME = MODE == 2, IMAGE = MODE == 0;
   extern __shared__ float4 smem[];
@@ -281,11 +282,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void pt_megakernel(const RenderParam
     if (DYN) {
       // every lane of the wave takes part: its own closest-hit ray first, then unstarted shadow rays of the wave (Scene.cpp:151-203)
 #ifdef MI_DYN_STATS
-      const float visible = traverse_dyn<QN, NS, MI_DYN_TH, false>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h, nullptr, nullptr, nullptr, dyn_stats);
+      const float visible = traverse_dyn<QN, NS, MI_DYN_TH, false, UNI>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h, nullptr, nullptr, nullptr, dyn_stats);
       ++dyn_stats[5];
 #else
       uint32_t trips = 0;
-      const float visible = traverse_dyn<QN, NS, MI_DYN_TH, COUNT>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h, &vis_c, &vis_s, &trips);
+      const float visible = traverse_dyn<QN, NS, MI_DYN_TH, COUNT, UNI>(sb, sv, stack, dyn, lane, alive, org, dir, pend, h, &vis_c, &vis_s, &trips);
       if (COUNT) trips_c += trips;  // wave-uniform: the trips of the unified loop (closest-hit and shadow rays together)
 #endif
       if (pend) { radiance = radiance + nee_saved * visible; pend = false; }  // PT.cpp:41: radiance += _connect(...) of the previous vertex
@@ -655,6 +656,9 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
 #define MI_PICK4TD(M, W, Q, B) (f2 == 0 ? pt_megakernel<false, M, false, W, Q, (B) | 0, true, true, true> : f2 == 1 ? pt_megakernel<false, M, false, W, Q, (B) | 1, true, true, true> : \
                                 f2 == 2 ? pt_megakernel<false, M, false, W, Q, (B) | 2, true, true, true> : pt_megakernel<false, M, false, W, Q, (B) | 3, true, true, true>)
 #define MI_PICKTD(M, W, Q) (feat == kFeatAll ? pt_megakernel<false, M, false, W, Q, kFeatAll, true, true, true> : (feat & kFeatLights) ? MI_PICK4TD(M, W, Q, kFeatLights) : MI_PICK4TD(M, W, Q, 0))
+#define MI_PICK4TDU(W, B) (f2 == 0 ? pt_megakernel<false, 0, false, W, 2, (B) | 0, true, true, true, false, true> : f2 == 1 ? pt_megakernel<false, 0, false, W, 2, (B) | 1, true, true, true, false, true> : \
+                           f2 == 2 ? pt_megakernel<false, 0, false, W, 2, (B) | 2, true, true, true, false, true> : pt_megakernel<false, 0, false, W, 2, (B) | 3, true, true, true, false, true>)
+#define MI_PICKTDU(W) (feat == kFeatAll ? pt_megakernel<false, 0, false, W, 2, kFeatAll, true, true, true, false, true> : (feat & kFeatLights) ? MI_PICK4TDU(W, kFeatLights) : MI_PICK4TDU(W, 0))
 #define MI_PICK_HBM(W, Q) (p.lds_tables ? (p.dyn_traverse ? (six ? MI_MODE2(MI_PICKTD(2, MI_DYN_W_HI, Q), MI_PICKTD(0, MI_DYN_W_HI, Q)) : MI_MODE2(MI_PICKTD(2, 5, Q), MI_PICKTD(0, 5, Q))) : MI_MODE2(MI_PICKT(2, W, Q), MI_PICKT(0, W, Q))) : MI_PICK_MODE(false, W, Q, true))
     const int feat = (p.features & uint32_t(kFeatPow)) ? kFeatAll : int(p.features);  // a general beta is rare: only the general variant has pow
     const int f2 = feat & 3;
@@ -670,9 +674,12 @@ hipError_t launch_megakernel(const RenderParams& p, bool lds_scene, int mode, bo
     else
     if (lds_scene) fn = p.stack_in_lds ? MI_PICK_MODE(true, MI_WAVES_LDS, 0, false) : MI_PICK_MODE(true, MI_WAVES_LDS, 0, true);  // shallow tree: stack without the spill path
     else if (p.wide_nodes == 2u) fn = MI_PICK_HBM(MI_WAVES_HBM, 0);
+    else if (large && mode == 0 && p.lds_tables && p.dyn_traverse && p.sv.dyn_uni) fn = six ? MI_PICKTDU(MI_DYN_W_HI) : MI_PICKTDU(5);  // wide records + one fetch per iteration
     else if (large) fn = MI_PICK_HBM(MI_WAVES_HBM_LARGE, 2);
     else fn = MI_PICK_HBM(MI_WAVES_HBM, 1);
 #undef MI_PICK_HBM
+#undef MI_PICKTDU
+#undef MI_PICK4TDU
 #undef MI_MODE2
 #undef MI_PICKF
 #undef MI_PICK4F

@@ -406,6 +406,11 @@ int mi_pt_create(const mi_scene_desc* desc, const mi_pt_params* params, int devi
                                area_collapse, &wide_need, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->sv.qnodes = h->qnodes; h->sv.qnodes4 = h->qnodes4;
+    // one fetch per iteration of the dynamic-fetch loop (pt_device.h traverse_dyn) where the walk is latency-bound: the wide records (about half as many as BVH2 nodes,
+    // 64 B each) fit the 4 MB L2 of an XCD.  Beyond that the same loop measured slower (atrium 269 k -2.8 %, 2 M -10 %: twice the L2 requests for equal fabric traffic).
+    // (clutter, 158 k triangles = 5 MB of records: +3.6 %; atrium 269 k = 8.6 MB: -2.8 %: the switch sits between them)
+    h->sv.dyn_uni = (uint64_t(n_nodes) * 32ull <= (13ull << 19)) ? 1u : 0u;
+    if (const char* e = std::getenv("MI_PT_DYN_UNI")) h->sv.dyn_uni = std::atoi(e) != 0 ? 1u : 0u;
     {  // absolute padding of centre / half-extent boxes (pt_device.h ce_box_test, traverse_flat): rays start within the scene box or at a camera
       double amax = 0.0;
       for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(double(h->info.scene_lo[a])), std::fabs(double(h->info.scene_hi[a]))));

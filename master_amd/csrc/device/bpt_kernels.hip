@@ -632,6 +632,244 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace(const RenderParams p,
 }
 
 // =====================================================================================================================
+// Stage A with PATH REGENERATION (r04, the default): bpt_trace above gives a lane one path — a wave runs as long as its longest light sub-path plus its
+// longest eye sub-path (3.5 vertices on average, dozens at the tail: 9 % of the lanes of an issued instruction were active, profiles/r04/pmc_bpt_livingroom.txt).
+// Here the two sub-paths are two kernels of resident waves, and a trip of a wave's loop extends every live sub-path by ONE vertex; a lane whose sub-path has
+// ended takes the next path of the launch from a cursor (one atomic per wave and trip), as pt_megakernel regenerates camera paths.  The loop bodies are
+// bpt_trace's, draw for draw: a path's records, counts and generator states are the same whatever lane walks it, everything downstream is unchanged.
+// Between the kernels a path's info[2 i] holds (L, generator state after the light sub-path, closest-hit rays so far, 1 = the path passed BPT.cpp:17-19).
+template <bool LIST, int QN, int WAVES = MI_BPT_TRACE_WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void bpt_trace_light(const RenderParams p, const BptState w) {
+  extern __shared__ float4 smem[];
+  SceneView sv = p.sv;
+  const float4* sb = sv.blob;
+  uint32_t scene_f4 = 0;
+  if (QN == 0) {
+    if (p.flat_k) { scene_f4 = flat_scene_f4(sv, p.flat_k); stage_scene_flat(smem, sv, p.flat_table, p.flat_k, threadIdx.x); }
+    else { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); }
+    sb = smem; __syncthreads();
+  }
+  TravStackT<(QN != 0)> stack;
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
+  stack.cap = p.stack_entries;
+  Ctx c; ctx_init(c, p, w, &stack, sb, &sv);
+  uint32_t* cursor = w.step_count + 4;
+  bool alive = false, ending = false, more = true, overflow = false;
+  uint32_t i = 0, size = 0, prv = 0;
+  Rng g; g.state = 0u;
+  LVert prev;
+  prev.surface.position = prev.surface.gnormal = prev.surface.tangent.c0 = prev.surface.tangent.c1 = prev.surface.tangent.c2 = F3(0, 0, 0);
+  prev.surface.material_id = 0u; prev.omega = prev.throughput = F3(0, 0, 0); prev.a = prev.A = 0.0f; prev.finite = 1;
+  for (;;) {
+    if (alive && ending) {  // BPT.cpp:178-189: the last vertex stays only if a path can be connected to it
+      const BSample last = bpt_bsdf_sample(c, g, prev.surface, prev.omega);
+      float4* lrec = w.lslab + size_t(i) * w.max_vertices * 7u;
+      if (last.q.finite == 0) --size; else rec_store_l(lrec + size_t(prv) * 7u, prev);
+      w.info[2 * size_t(i)] = make_uint4(size, g.state, c.n_basic, 1u);
+      alive = false;
+    }
+    for (;;) {  // idle lanes take the next paths of the launch; a path that ends before its first vertex (19 % of them) leaves the lane idle for another round
+      const bool want = !alive && more;
+      const uint64_t m = __ballot(want);
+      if (m == 0ull) break;
+      uint32_t base = 0u;
+      const uint32_t leader = uint32_t(__builtin_ctzll(m));
+      if ((threadIdx.x & 63u) == leader) base = atomicAdd(cursor, uint32_t(__popcll(m)));
+      base = uint32_t(__shfl(int(base), int(leader), 64));
+      if (want) {
+        i = base + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+        if (i >= w.lanes) more = false;
+        else {
+          const Lane ln = lane_decode<LIST>(p, w, i);
+          uint4 res = make_uint4(0u, 0u, 0u, 0u);
+          if (ln.ok) {
+            g = rng_seed(p.seed, ln.py * p.width + ln.px, ln.sample);
+            (void)rng_f(g); (void)rng_f(g);  // the camera sample's two draws come first (bpt_trace_eye draws them again)
+            if (!bpt_roulette(c, g)) {  // BPT.cpp:17-19
+              res = make_uint4(0u, 0u, 0u, 1u);
+              if (!bpt_roulette(c, g)) {  // _traceLight (BPT.cpp:121-190)
+                const LSample ls = light_sample(c, g);
+                prev = sample_to_vertex(c, ls);
+                size = 1u; prv = 0u; c.n_basic = 0u; alive = true; ending = false;
+              }
+              res.y = g.state;
+            }
+          }
+          if (!alive) w.info[2 * size_t(i)] = res;
+        }
+      }
+    }
+    if (!__any(alive)) break;  // no lane holds a sub-path and none could take a path: the launch is dealt
+    if (alive && !ending) {
+      if (bpt_roulette(c, g)) ending = true;
+      else {
+        const BSample b = bpt_bsdf_sample(c, g, prev.surface, prev.omega);
+        const Surf surface = scene_intersect<QN>(c, prev.surface, b.omega, 1u << MI_ENTITY_MESH);
+        if (surface.material_id == 0xFFFFFFFFu) ending = true;
+        else if (size >= w.max_vertices) { overflow = true; ending = true; }
+        else {
+          LVert cur;
+          cur.surface = surface;
+          cur.omega = -b.omega;
+          const Edge e = make_edge(prev.surface, cur.surface, cur.omega);
+          cur.throughput = ((prev.throughput * b.q.throughput) * e.bCos) * c.rinv;
+          if (l1norm(cur.throughput) < MI_FLT_EPSILON) ending = true;
+          else {
+            cur.throughput = cur.throughput / b.q.density;
+            prev.finite = prev.finite < b.q.finite ? prev.finite : b.q.finite;
+            cur.finite = b.q.finite;
+            cur.a = 1.0f / betaf(c, e.fG * b.q.density);
+            cur.A = (prev.A * betaf(c, b.q.densityRev) + prev.a * float(prev.finite)) * betaf(c, e.bG) * cur.a;
+            if (b.q.finite == 0) { prev = cur; }
+            else { rec_store_l(w.lslab + (size_t(i) * w.max_vertices + prv) * 7u, prev); prev = cur; prv = size; ++size; }
+          }
+        }
+      }
+    }
+  }
+  uint32_t o = overflow ? 1u : 0u;
+  for (int k = 32; k > 0; k >>= 1) o += __shfl_xor(o, k, 64);
+  if (o && (threadIdx.x & 63u) == 0 && p.counters) atomicAdd(&p.counters[15], (unsigned long long)o);
+}
+
+template <bool LIST, int QN, int WAVES = MI_BPT_TRACE_WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void bpt_trace_eye(const RenderParams p, const BptState w) {
+  extern __shared__ float4 smem[];
+  SceneView sv = p.sv;
+  const float4* sb = sv.blob;
+  uint32_t scene_f4 = 0;
+  if (QN == 0) {
+    if (p.flat_k) { scene_f4 = flat_scene_f4(sv, p.flat_k); stage_scene_flat(smem, sv, p.flat_table, p.flat_k, threadIdx.x); }
+    else { scene_f4 = lds_scene_f4(sv); stage_scene_to_lds(smem, sv, threadIdx.x); }
+    sb = smem; __syncthreads();
+  }
+  TravStackT<(QN != 0)> stack;
+  stack.lds = (lds_u32*)(reinterpret_cast<uint32_t*>(smem + scene_f4) + threadIdx.x);
+  stack.cap = p.stack_entries;
+  Ctx c; ctx_init(c, p, w, &stack, sb, &sv);
+  uint32_t* cursor = w.step_count + 5;
+  const m33 v2w = {F3(p.v2w[0], p.v2w[1], p.v2w[2]), F3(p.v2w[3], p.v2w[4], p.v2w[5]), F3(p.v2w[6], p.v2w[7], p.v2w[8])};
+  Surf cs;  // Technique::_camera_surface (Technique.cpp:107-116)
+  cs.position = F3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+  cs.tangent.c0 = v2w.c1; cs.tangent.c1 = -v2w.c2; cs.tangent.c2 = v2w.c0;
+  cs.material_id = (0u << 2) | MI_ENTITY_CAMERA;
+  cs.gnormal = -v2w.c2;
+  bool alive = false, more = true, overflow = false;
+  uint32_t i = 0, L = 0, E = 0, n_items = 0, n_em = 0, n_dir = 0, pxy = 0, flk = 0;
+  Rng g; g.state = 0u;
+  EVert prev;
+  prev.surface = cs; prev.omega = prev.throughput = F3(0, 0, 0); prev.c = prev.C = 0.0f; prev.finite = 1;
+  for (;;) {
+    for (;;) {
+      const bool want = !alive && more;
+      const uint64_t m = __ballot(want);
+      if (m == 0ull) break;
+      uint32_t base = 0u;
+      const uint32_t leader = uint32_t(__builtin_ctzll(m));
+      if ((threadIdx.x & 63u) == leader) base = atomicAdd(cursor, uint32_t(__popcll(m)));
+      base = uint32_t(__shfl(int(base), int(leader), 64));
+      if (want) {
+        i = base + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+        if (i >= w.lanes) more = false;
+        else {
+          const Lane ln = lane_decode<LIST>(p, w, i);
+          pxy = (ln.py << 16) | ln.px; flk = (ln.fl << 1) | (ln.ok ? 1u : 0u);
+          uint4 res = make_uint4(0u, 0u, 0u, 0u);
+          if (ln.ok) res = w.info[2 * size_t(i)];
+          if (res.w != 0u) {
+            g = rng_seed(p.seed, ln.py * p.width + ln.px, ln.sample);
+            const float u0 = rng_f(g), u1 = rng_f(g);
+            const float fx = float(ln.px) + u0, fy = float(ln.py) + u1;
+            const float vx = fx * p.res_y_inv * 2.0f - p.res_x * p.res_y_inv;
+            const float vy = fy * p.res_y_inv * 2.0f - 1.0f;
+            const f3 dir = mulmv(v2w, normalize(F3(vx, vy, -p.focal_length_y)));
+            g.state = res.y; L = res.x; c.n_basic = res.z;
+            E = 0u; n_items = 0u; n_em = 0u; n_dir = 0u;
+            prev.surface = cs; prev.omega = -dir; prev.throughput = F3(1, 1, 1) * c.rinv;
+            prev.finite = 1; prev.c = 0.0f; prev.C = 0.0f;
+            alive = true;
+          } else {
+            w.info[2 * size_t(i)] = make_uint4(0u, 0u, 0u, 0u);
+            w.info[2 * size_t(i) + 1] = make_uint4(0u, 0u, pxy, flk);
+            w.item_offset[i] = 0u;
+          }
+        }
+      }
+    }
+    if (!__any(alive)) break;
+    if (alive) {  // one vertex of _traceEye without the connections (BPT.cpp:24-98)
+      float4* erec = w.eslab + size_t(i) * w.max_vertices * 7u;
+      float4* nrec = w.nslab + size_t(i) * w.max_vertices * 7u;
+      float4* em = w.emission + size_t(i) * w.max_vertices;
+      uint2* evi = w.evinfo + size_t(i) * w.max_vertices;
+      bool ended = false;
+      if (E >= w.max_vertices) { overflow = true; ended = true; }
+      else {
+        const bool at_camera = (prev.surface.material_id & 3u) == MI_ENTITY_CAMERA;
+        if (at_camera) {
+          rec_store_e(erec + size_t(E) * 7u, prev, 0u, 0u);  // items [0, L): the splats of _connect_eye
+          evi[E] = make_uint2(0u, 0u);
+          n_items = L;
+        } else {
+          uint32_t kind = 0;
+          if (!bpt_roulette(c, g)) {  // BPT.cpp:278-288
+            const LSample b = light_sample(c, g);
+            if (!b.directional) { kind = 1; rec_store_l(nrec + size_t(E) * 7u, sample_to_vertex(c, b)); }
+            else { kind = 2; rec_store_dir(nrec + size_t(E) * 7u, b); ++n_dir; }
+          }
+          rec_store_e(erec + size_t(E) * 7u, prev, kind, n_items);
+          evi[E] = make_uint2(kind, n_items);
+          n_items += (kind ? 1u : 0u) + (L > 1u ? L - 1u : 0u);
+        }
+        const uint32_t k = E;
+        ++E;
+        const BSample b = bpt_bsdf_sample(c, g, prev.surface, prev.omega);
+        Surf surface = prev.surface;
+        EVert cur = prev;
+        for (;;) {
+          surface = scene_intersect<QN>(c, surface, b.omega, 0xFFFFFFFFu);
+          if (surface.material_id == 0xFFFFFFFFu) {
+            if (at_camera) {  // BPT.cpp:49-51
+              const f3 sky = (c.sky_horizon * (1 - b.omega.z) + c.sky_zenith * b.omega.z) * c.rinv;
+              em[0] = make_float4(sky.x, sky.y, sky.z, __uint_as_float(0u)); n_em = 1;
+            }
+            ended = true; break;
+          }
+          cur.surface = surface; cur.omega = -b.omega;
+          const Edge e = make_edge(prev.surface, cur.surface, cur.omega);
+          cur.throughput = (prev.throughput * b.q.throughput) * e.bCos;
+          if (l1norm(cur.throughput) < MI_FLT_EPSILON) { ended = true; break; }
+          cur.throughput = cur.throughput / b.q.density;
+          prev.finite = prev.finite < b.q.finite ? prev.finite : b.q.finite;
+          cur.finite = b.q.finite;
+          cur.c = 1.0f / betaf(c, e.fG * b.q.density);
+          cur.C = (prev.C * betaf(c, b.q.densityRev) + prev.c * float(prev.finite)) * betaf(c, e.bG) * cur.c;
+          if (surf_is_light(surface)) {
+            const f3 t = bpt_connect_light(c, cur);
+            if (n_em >= w.max_vertices) { overflow = true; ended = true; break; }
+            em[n_em++] = make_float4(t.x, t.y, t.z, __uint_as_float(k));
+          } else break;
+        }
+        if (!ended) {
+          prev = cur;
+          if (bpt_roulette(c, g)) ended = true;
+          else prev.throughput = prev.throughput * c.rinv;
+        }
+      }
+      if (ended) {
+        w.info[2 * size_t(i)] = make_uint4(L, E, n_items, n_em);
+        w.info[2 * size_t(i) + 1] = make_uint4(c.n_basic, n_dir, pxy, flk);
+        w.item_offset[i] = n_items;
+        alive = false;
+      }
+    }
+  }
+  uint32_t o = overflow ? 1u : 0u;
+  for (int k = 32; k > 0; k >>= 1) o += __shfl_xor(o, k, 64);
+  if (o && (threadIdx.x & 63u) == 0 && p.counters) atomicAdd(&p.counters[15], (unsigned long long)o);
+}
+
+// =====================================================================================================================
 // Stage A as UNIFORM STEPS (r04; scenes read from HBM).  bpt_trace above walks a whole light sub-path and a whole eye sub-path per lane: a wave runs as
 // long as its longest sub-path (3.5 vertices on average, dozens at the tail) and every scene_intersect is a per-lane tree walk inside that loop —
 // 9 % of the lanes of an issued instruction were active (profiles/r03/pmc_bpt_livingroom.txt).  Here a path is a coroutine that is suspended at each
@@ -1546,9 +1784,33 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
   }
   else if (p.wide_nodes == 1u) fn = list ? bpt_trace<true, 2> : bpt_trace<false, 2>;
   else fn = list ? bpt_trace<true, 1> : bpt_trace<false, 1>;
+  // r04: the two sub-paths as two kernels of resident waves with path regeneration (bpt_trace_light / bpt_trace_eye) where they pay — the models walked at six
+  // waves per SIMD (profiles/r04/ab_bpt_steps.txt #4: LivingRoomLit 205 -> 188 ms, MetalRings +-0; scenes in LDS 67 -> 99 ms: a launch holds four paths per resident
+  // lane and the longest sub-path, ~140 vertices, lasts as long as the rest of the kernel — twice with two kernels).  MI_BPT_PERSIST=0 / 1 forces one lane per path / this form.
+  bool persist = !lds_scene && p.sv.n_tris >= 16384u;
+  if (const char* v = std::getenv("MI_BPT_PERSIST")) persist = std::atoi(v) != 0 && !lds_scene;
+  if (persist && w.step_count) {
+    void (*fl)(const RenderParams, const BptState) = nullptr;
+    void (*fe)(const RenderParams, const BptState) = nullptr;
+    const uint32_t waves = 6u;
+    if (p.wide_nodes == 1u) { fl = list ? bpt_trace_light<true, 2, 6> : bpt_trace_light<false, 2, 6>; fe = list ? bpt_trace_eye<true, 2, 6> : bpt_trace_eye<false, 2, 6>; }
+    else { fl = list ? bpt_trace_light<true, 1, 6> : bpt_trace_light<false, 1, 6>; fe = list ? bpt_trace_eye<true, 1, 6> : bpt_trace_eye<false, 1, 6>; }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fl), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fe), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    static const uint32_t n_cu = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return uint32_t(v); }();
+    uint32_t blocks = n_cu * waves * 4u / (kBlock / 64u);  // resident waves only: waves per SIMD x 4 SIMDs / waves per workgroup = workgroups per CU
+    if (blocks > grid.x) blocks = grid.x;
+    e = hipMemsetAsync(w.step_count + 4, 0, 2 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fl, dim3(blocks), block, lds, stream, p, w);
+    hipLaunchKernelGGL(fe, dim3(blocks), block, lds, stream, p, w);
+  } else {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, grid, block, lds, stream, p, w);
+  }
   {
     const uint32_t total = w.lanes + 1u, tiles = (total + kScanTile - 1u) / kScanTile;
     hipLaunchKernelGGL(bpt_scan_tiles, dim3(tiles), dim3(256), 0, stream, w.item_offset, total, w.scan_tmp);

@@ -10,6 +10,9 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <chrono>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "device/launch.h"
@@ -1335,20 +1338,26 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
   bool overflow = false;
   int rc = run(w, &overflow);
   if (rc || !overflow) return rc;
-  // A sub-path outgrew the slab share of this launch (long paths: roulette close to 1).  The same memory holds fewer paths at
-  // the reference's own capacity of 1024 vertices (BPT.hpp:30): redo the launch in slices.
-  const uint64_t slice = uint64_t(w.lanes) * w.max_vertices / 1024u;
-  if (slice == 0 || w.max_vertices >= 1024u) return fail(MI_ERR_UNSUPPORTED, "BPT: a sub-path exceeds 1024 vertices (the reference's fixed_vector capacity)");
-  const uint32_t first = w.first, lanes = w.lanes;
-  for (uint32_t done = 0; done < lanes; done += uint32_t(slice)) {
-    mi::BptState ws = w;
-    ws.first = first + done; ws.lanes = lanes - done < slice ? lanes - done : uint32_t(slice); ws.max_vertices = 1024u;
-    bool again = false;
-    rc = run(ws, &again);
-    if (rc) return rc;
-    if (again) return fail(MI_ERR_UNSUPPORTED, "BPT: a sub-path exceeds 1024 vertices (the reference's fixed_vector capacity)");
-  }
-  return MI_OK;
+  // A sub-path outgrew the slab share of this launch (long paths: roulette close to 1, or little free memory).  The same memory holds fewer paths at a
+  // larger capacity: redo the launch in slices at four times the capacity (r04: not at once at the reference's 1024 vertices, BPT.hpp:30 — with a share of 32
+  // vertices that was 32 slices per launch, 5 s instead of 0.12 s for 64 frames of CornellBoxSpecular when another handle held most of the device), and a
+  // slice that still overflows again at four times its own, up to 1024.
+  std::function<int(const mi::BptState&)> redo = [&](const mi::BptState& wf) -> int {
+    if (wf.max_vertices >= 1024u) return fail(MI_ERR_UNSUPPORTED, "BPT: a sub-path exceeds 1024 vertices (the reference's fixed_vector capacity)");
+    const uint32_t cap = wf.max_vertices * 4u > 1024u ? 1024u : wf.max_vertices * 4u;
+    const uint64_t slice = uint64_t(wf.lanes) * wf.max_vertices / cap;
+    if (slice == 0) return fail(MI_ERR_UNSUPPORTED, "BPT: a sub-path exceeds the vertex slab of a single path");
+    for (uint32_t done = 0; done < wf.lanes; done += uint32_t(slice)) {
+      mi::BptState ws = wf;
+      ws.first = wf.first + done; ws.lanes = wf.lanes - done < slice ? wf.lanes - done : uint32_t(slice); ws.max_vertices = cap;
+      bool again = false;
+      int r = run(ws, &again);
+      if (r) return r;
+      if (again) { r = redo(ws); if (r) return r; }
+    }
+    return MI_OK;
+  };
+  return redo(w);
 }
 // buffers and per-launch constants shared by the two BPT entry points
 int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint64_t total_lanes, mi::RenderParams& p, mi::BptState& w,
@@ -1390,12 +1399,25 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
       const uint64_t have = staged ? h->bpt_arena_bytes : h->bpt_slab_bytes;  // what this handle already holds counts as available to it
+      // the memory of a process that has just exited (or of a handle destroyed a moment ago) comes back asynchronously: seen as 64 frames in 5 s instead of 0.12 s
+      // because the share was 16 vertices per sub-path.  While the free figure is small AND still growing, wait for it (at most 2 s).
+      for (int k = 0; k < 20 && (uint64_t(free_b) + have) * 2 / 5 / (staged ? 3 : 1) < (6ull << 30); ++k) {  // < 192 vertices for 2^18 paths
+        size_t f2 = 0, t2 = 0;
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        if (hipMemGetInfo(&f2, &t2) != hipSuccess) break;
+        const bool growing = f2 > free_b + (64u << 20);
+        free_b = f2;
+        if (!growing && k >= 2) break;
+      }
       const uint64_t share = (uint64_t(free_b) + have) * 2 / 5 / (staged ? 3 : 1);
       if (share < budget) budget = share;
     }
   }
   if (const char* e = std::getenv("MI_BPT_SLAB_MB")) { const long long v = std::atoll(e); if (v > 0) budget = uint64_t(v) << 20; }
   uint64_t cap = budget / (lanes * 112ull);
+  // little memory (another handle or process holds the device): fewer paths per launch before a short slab — a sub-path of more than 192 vertices is a 2e-9
+  // event at roulette 0.9, one of more than 80 happens in every launch, and an overflowing launch is redone in slices (bpt_launch)
+  while (cap < 192 && lanes > (1ull << 18)) { lanes = (lanes / 2 + 255) / 256 * 256; cap = budget / (lanes * 112ull); }
   if (cap > 1024) cap = 1024;
   if (cap < 16) cap = 16;
   for (;;) {  // an allocation that fails is retried at half the capacity, then at half the paths per launch, down to 16 vertices x 256 paths

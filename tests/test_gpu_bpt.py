@@ -186,6 +186,30 @@ def test_bpt_tracing_stage_as_uniform_steps_is_bit_identical_per_path(monkeypatc
         assert np.array_equal(np.asarray(b[2])[:3000], np.asarray(o[2])) and _bits_equal(b[0][:3000], o[0]).all() and _bits_equal(b[1][:3000], o[1]).all()
 
 
+@pytest.mark.parametrize("name,wide", [("LivingRoomLit", 1), ("CornellBoxSpecular", 1), ("MetalRings", 0), ("TestCase10", 1)])
+def test_bpt_tracing_stage_with_path_regeneration_is_bit_identical_per_path(monkeypatch, name, wide):
+    """r04: the tracing stage as two kernels of resident waves (bpt_trace_light, bpt_trace_eye): a trip extends every live sub-path by one vertex and a lane
+    whose sub-path has ended takes the launch's next path from a cursor; between the kernels a path's generator state and light sub-path length wait in its
+    info record.  Whatever lane walks a path, its draws, records and counts are the per-lane form's (MI_BPT_PERSIST=0) and the oracle's.  Default for the
+    models walked at six waves per SIMD (LivingRoomLit 205 -> 188 ms per 64 frames), forced here on every model read from HBM."""
+    s = load_scene(name)
+    pt = ma.PathTracing(s, beta=2.0)
+    xy, si = _paths(64, 48, 12000, 23)
+    monkeypatch.setenv("MI_PT_WIDE_NODES", str(wide))
+    monkeypatch.setenv("MI_BPT_PERSIST", "0")
+    a = pt.bpt_trace_paths(64, 48, xy, si, seed=8)
+    img_a = pt.bpt_render_rgbn(40, 30, spp=5, seed=3)
+    monkeypatch.setenv("MI_BPT_PERSIST", "1")
+    b = pt.bpt_trace_paths(64, 48, xy, si, seed=8)
+    img_b = pt.bpt_render_rgbn(40, 30, spp=5, seed=3)
+    assert np.array_equal(a[2], b[2]) and _bits_equal(a[0], b[0]).all() and _bits_equal(a[1], b[1]).all()
+    assert np.array_equal(img_a[..., 3], img_b[..., 3])
+    np.testing.assert_allclose(img_a, img_b, rtol=2e-6, atol=0)  # FP64 splat order is free
+    if name in ("CornellBoxSpecular", "MetalRings"):  # and against the oracle directly
+        o = oracle.Oracle(s, beta=2.0).bpt_trace_paths(64, 48, xy[:3000], si[:3000], seed=8)
+        assert np.array_equal(np.asarray(b[2])[:3000], np.asarray(o[2])) and _bits_equal(b[0][:3000], o[0]).all() and _bits_equal(b[1][:3000], o[1]).all()
+
+
 def test_bpt_visibility_stage_against_the_oracle(monkeypatch):
     """the forced visibility stage against the CPU oracle directly (not only against the other device form)"""
     monkeypatch.setenv("MI_BPT_DYN_VIS", "1")

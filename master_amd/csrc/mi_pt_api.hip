@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -133,9 +134,17 @@ float l1(const float* v) { return std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(
 
 int ensure(void** p, size_t* have, size_t need) {
   if (*have >= need) return MI_OK;
+  const bool debug = std::getenv("MI_BPT_DEBUG") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   if (*p) hipFree(*p);
+  const auto t1 = std::chrono::steady_clock::now();
   *p = nullptr; *have = 0;
   HIP_TRY(hipMalloc(p, need));
+  if (debug) {
+    const auto t2 = std::chrono::steady_clock::now();
+    const double f = std::chrono::duration<double, std::milli>(t1 - t0).count(), m = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    if (f + m > 20.0) std::fprintf(stderr, "[mi_pt] ensure(%zu bytes): hipFree %.1f ms, hipMalloc %.1f ms\n", need, f, m);
+  }
   *have = need;
   return MI_OK;
 }
@@ -1303,6 +1312,8 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
   const bool lds = use_lds_scene(h) && h->stack_fits_lds;  // small scenes with shallow trees: padded copy of the blob in LDS, binary walk, stack without a spill path
   auto run = [&](mi::BptState& ws, bool* overflow) -> int {
     uint32_t total = 0;
+    const bool debug = std::getenv("MI_BPT_DEBUG") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     // r04: scenes read from HBM trace their sub-paths as uniform steps (bpt_step / bpt_closest rounds, bpt_kernels.hip) instead of one lane walking both
     // sub-paths of its path; MI_BPT_STEPS=0/1 forces the per-lane form / the steps (the kernels of LDS-resident scenes always walk per lane)
     bool steps = false;  // measured (profiles/r04/ab_bpt_steps.txt): not yet ahead of the per-lane form — opt-in
@@ -1312,9 +1323,13 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
     if (steps && steps_mode == 2) { uint32_t rounds = 0; HIP_TRY(bl.trace_passes(p, ws, list, stream, &total, &rounds)); h->bpt_step_rounds = rounds; }
     else if (steps) { uint32_t rounds = 0; HIP_TRY(bl.trace_steps(p, ws, list, stream, &total, &rounds)); h->bpt_step_rounds = rounds; }
     else { HIP_TRY(bl.trace(p, ws, list, lds, stream, &total)); h->bpt_step_rounds = 0; }
+    const auto t_trace = std::chrono::steady_clock::now();
     unsigned long long over = 0;
     HIP_TRY(hipMemcpy(&over, h->d_counters + 15, sizeof over, hipMemcpyDeviceToHost));
-    if (over) { *overflow = true; HIP_TRY(hipMemsetAsync(h->d_counters + 15, 0, sizeof over, stream)); return MI_OK; }
+    if (over) {
+      if (std::getenv("MI_BPT_DEBUG")) std::fprintf(stderr, "[mi_bpt] %llu sub-paths outgrew %u vertices in a launch of %u paths: redone in slices\n", over, ws.max_vertices, ws.lanes);
+      *overflow = true; HIP_TRY(hipMemsetAsync(h->d_counters + 15, 0, sizeof over, stream)); return MI_OK;
+    }
     // The visibility stage pays where a launch holds many more shadow rays than the chip has lanes (524 288 resident) and a node is a dependent
     // fetch from L2 / HBM: LivingRoomLit (20 M items per launch) +13 %, CornellBoxSpecular (5 M) +8 %; MetalRings (0.6 M) -4 %, scenes walked
     // in LDS -8 % (profiles/r02/ab_bpt_visibility.txt).  MI_BPT_DYN_VIS=0/1 forces it off / on.
@@ -1323,8 +1338,12 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
     // values [items][16 B]; with the visibility stage also: shadow rays [items][32 B] | occlusion bytes [items] | ray count + chunk cursor
     // (launches without it — LDS-resident scenes, fewer than 2 M items — hold the values alone: a third of the bytes)
     const size_t n_it = total ? total : 1, occl_bytes = ws.dyn_vis ? (n_it + 255) / 256 * 256 : 0;
-    int rc = ensure(reinterpret_cast<void**>(&h->bpt_values), &h->bpt_values_bytes, n_it * (ws.dyn_vis ? 48 : 16) + occl_bytes + 256);
+    // grown with a quarter of headroom: the item count moves a few per cent from launch to launch, and an allocation made while the driver is still clearing
+    // the memory of a handle destroyed a moment ago waits for it (seen: 3.5 s for 0.9 GB after a 116 GB arena was freed; MI_BPT_DEBUG=1 prints such waits)
+    const size_t values_need = n_it * (ws.dyn_vis ? 48 : 16) + occl_bytes + 256;
+    int rc = h->bpt_values_bytes >= values_need ? MI_OK : ensure(reinterpret_cast<void**>(&h->bpt_values), &h->bpt_values_bytes, values_need + values_need / 4);
     if (rc) return rc;
+    const auto t_ensure = std::chrono::steady_clock::now();
     ws.values = h->bpt_values;
     ws.rays = ws.dyn_vis ? h->bpt_values + n_it : nullptr;
     ws.occl = ws.dyn_vis ? reinterpret_cast<uint8_t*>(h->bpt_values + 3 * n_it) : nullptr;
@@ -1333,6 +1352,14 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
     if (const char* e = std::getenv("MI_BPT_VIS_TH")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ws.vis_th = uint32_t(v); }
     if (const char* e = std::getenv("MI_BPT_VIS_WIDE")) ws.vis_wide = std::atoi(e) != 0 ? 1u : 0u;
     HIP_TRY(bl.connect(p, ws, list, lds, total, stream));
+    if (debug) {
+      HIP_TRY(hipStreamSynchronize(stream));
+      const auto t_end = std::chrono::steady_clock::now();
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      if (ms(t_begin, t_end) > 50.0)
+        std::fprintf(stderr, "[mi_bpt] slow launch: trace %.1f ms, overflow read + buffers %.1f ms, connect %.1f ms (%u items, %zu values bytes)\n", ms(t_begin, t_trace), ms(t_trace, t_ensure),
+                     ms(t_ensure, t_end), total, h->bpt_values_bytes);
+    }
     return MI_OK;
   };
   bool overflow = false;
@@ -1455,6 +1482,11 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     else return rc;
   }
   *lanes_per_launch = uint32_t(lanes);
+  if (std::getenv("MI_BPT_DEBUG")) {
+    size_t f = 0, t = 0; (void)hipMemGetInfo(&f, &t);
+    std::fprintf(stderr, "[mi_bpt] paths per launch %llu, vertices per sub-path %u, slab budget %.1f GB, device free %.1f of %.1f GB, arena %.1f GB\n", (unsigned long long)lanes,
+                 w.max_vertices, double(budget) / 1073741824.0, double(f) / 1073741824.0, double(t) / 1073741824.0, double(h->bpt_arena_bytes) / 1073741824.0);
+  }
   p.counters = h->d_counters;
   return MI_OK;
 }

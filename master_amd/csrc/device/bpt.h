@@ -15,6 +15,7 @@ struct BptState {
   uint32_t frame;          // image mode: sample index of the first frame of this batch (added to RenderParams::sample_offset)
   uint32_t frames;         // image mode: frames in this batch (each with its own eye / light image)
   uint32_t max_vertices;   // capacity of a lane's light sub-path (BPT.hpp:30 allows 1024)
+  uint32_t async_total;    // 1: bpt_stage_trace leaves the item count's copy to the (pinned) host word in flight instead of waiting for it (launches overlapped on several streams)
   float4* slab;            // one-kernel form: [max_vertices][7][lanes] light sub-path vertices
   // staged form: path-major records (7 float4 per vertex), emission terms, per-path info, item offsets and values
   float4* lslab; float4* eslab; float4* nslab;   // [lanes][max_vertices][7]: light vertices, eye vertices, NEE samples of the eye vertices

@@ -1819,6 +1819,7 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
   }
   e = hipMemcpyAsync(total_items, w.item_offset + w.lanes, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
   if (e != hipSuccess) return e;
+  if (w.async_total) return hipGetLastError();  // the caller waits for this stream when it needs the count (mi_bpt_render: launches in flight on several streams)
   e = hipStreamSynchronize(stream);
   if (e != hipSuccess) return e;
   return hipGetLastError();

@@ -71,6 +71,13 @@ struct mi_pt_handle {
   float4* bpt_slab = nullptr; size_t bpt_slab_bytes = 0;
   char* bpt_arena = nullptr; size_t bpt_arena_bytes = 0;      // staged form: slabs, emission terms, path info, item offsets
   float4* bpt_values = nullptr; size_t bpt_values_bytes = 0;  // staged form: connection item values
+  // launches in flight (mi_bpt_render, r04): each flight has a stream, the event of its last launch, its connection values and two pinned host words
+  // (item count, overflow count) of its launch in flight
+  static constexpr uint32_t kBptFlights = 4;
+  struct BptFlight { hipStream_t stream = nullptr; hipEvent_t done = nullptr; float4* values = nullptr; size_t values_bytes = 0; };
+  BptFlight bpt_flight[kBptFlights];
+  unsigned long long* bpt_pinned = nullptr;  // [kBptFlights][2]
+  hipEvent_t bpt_fork = nullptr;             // h->stream -> the flights' streams
   float* bpt_eye = nullptr; size_t bpt_eye_bytes = 0;
   double* bpt_light = nullptr; size_t bpt_light_bytes = 0;
   float sphere[4] = {0, 0, 0, 0};
@@ -598,6 +605,13 @@ void mi_pt_destroy(mi_pt_handle* h) {
   if (h->bpt_slab) D(hipFree(h->bpt_slab));
   if (h->bpt_arena) D(hipFree(h->bpt_arena));
   if (h->bpt_values) D(hipFree(h->bpt_values));
+  for (auto& fl : h->bpt_flight) {
+    if (fl.values) D(hipFree(fl.values));
+    if (fl.done) D(hipEventDestroy(fl.done));
+    if (fl.stream) D(hipStreamDestroy(fl.stream));
+  }
+  if (h->bpt_pinned) D(hipHostFree(h->bpt_pinned));
+  if (h->bpt_fork) D(hipEventDestroy(h->bpt_fork));
   if (h->bpt_eye) D(hipFree(h->bpt_eye));
   if (h->bpt_light) D(hipFree(h->bpt_light));
   if (h->d_rgbn) D(hipFree(h->d_rgbn));
@@ -1387,8 +1401,9 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
   return redo(w);
 }
 // buffers and per-launch constants shared by the two BPT entry points
+// flights > 1 (mi_bpt_render): the launch's paths and the arena are dealt to `flights` launches in flight; w is the first one's state, more[0 .. flights - 2] the others'
 int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint64_t total_lanes, mi::RenderParams& p, mi::BptState& w,
-                uint32_t* lanes_per_launch) {
+                uint32_t* lanes_per_launch, uint32_t flights = 1, mi::BptState* more = nullptr) {
   std::memset(&p, 0, sizeof p); std::memset(&w, 0, sizeof w);
   int rc = fill_camera(h, camera_id, width, height, p);
   if (rc) return rc;
@@ -1447,28 +1462,35 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   while (cap < 192 && lanes > (1ull << 18)) { lanes = (lanes / 2 + 255) / 256 * 256; cap = budget / (lanes * 112ull); }
   if (cap > 1024) cap = 1024;
   if (cap < 16) cap = 16;
+  uint64_t lanes_flight = lanes;
   for (;;) {  // an allocation that fails is retried at half the capacity, then at half the paths per launch, down to 16 vertices x 256 paths
     w.max_vertices = uint32_t(cap);
     if (staged) {
-      const size_t slab = size_t(lanes) * cap * 112;
-      const size_t step_bytes = size_t(lanes) * (mi::kBptStepF4 * 16 + 32 + 16 + 8) + 4096;  // tracing stage as uniform steps: state, ray, hit, two index lists per path
-      const size_t need = 3 * slab + size_t(lanes) * (cap * 24 + 32 + 4 + 1) + 8192 + step_bytes;
+      const uint64_t lf = flights > 1 ? (lanes / flights / 256 * 256 > 256 ? lanes / flights / 256 * 256 : 256) : lanes;  // paths of one launch in flight
+      lanes_flight = lf;
+      const size_t slab = size_t(lf) * cap * 112;
+      const size_t step_bytes = size_t(lf) * (mi::kBptStepF4 * 16 + 32 + 16 + 8) + 4096;  // tracing stage as uniform steps: state, ray, hit, two index lists per path
+      const size_t need = (3 * slab + size_t(lf) * (cap * 24 + 32 + 4 + 1) + 16384 + step_bytes) * flights;
       rc = ensure(reinterpret_cast<void**>(&h->bpt_arena), &h->bpt_arena_bytes, need);
       if (rc == MI_OK) {
         char* a = h->bpt_arena;
         auto take = [&](size_t bytes) { char* r = a; a += (bytes + 255) / 256 * 256; return r; };
-        w.lslab = reinterpret_cast<float4*>(take(slab)); w.eslab = reinterpret_cast<float4*>(take(slab)); w.nslab = reinterpret_cast<float4*>(take(slab));
-        w.emission = reinterpret_cast<float4*>(take(size_t(lanes) * cap * 16));
-        w.evinfo = reinterpret_cast<uint2*>(take(size_t(lanes) * cap * 8));
-        w.info = reinterpret_cast<uint4*>(take(size_t(lanes) * 32));
-        w.item_offset = reinterpret_cast<uint32_t*>(take((size_t(lanes) + 1) * 4));
-        w.scan_tmp = reinterpret_cast<uint32_t*>(take((size_t(lanes) / 2048 + 2) * 4));
-        w.step_state = reinterpret_cast<float4*>(take(size_t(lanes) * mi::kBptStepF4 * 16));
-        w.step_rays = reinterpret_cast<float4*>(take(size_t(lanes) * 32));
-        w.step_hits = reinterpret_cast<float4*>(take(size_t(lanes) * 16));
-        w.step_active[0] = reinterpret_cast<uint32_t*>(take(size_t(lanes) * 4));
-        w.step_active[1] = reinterpret_cast<uint32_t*>(take(size_t(lanes) * 4));
-        w.step_count = reinterpret_cast<uint32_t*>(take(1024));  // [0..1] list counts, [8..71] chunk cursors of the walking waves
+        for (uint32_t f = 0; f < flights; ++f) {
+          mi::BptState& ws = f == 0 ? w : more[f - 1];
+          if (f) ws = w;
+          ws.lslab = reinterpret_cast<float4*>(take(slab)); ws.eslab = reinterpret_cast<float4*>(take(slab)); ws.nslab = reinterpret_cast<float4*>(take(slab));
+          ws.emission = reinterpret_cast<float4*>(take(size_t(lf) * cap * 16));
+          ws.evinfo = reinterpret_cast<uint2*>(take(size_t(lf) * cap * 8));
+          ws.info = reinterpret_cast<uint4*>(take(size_t(lf) * 32));
+          ws.item_offset = reinterpret_cast<uint32_t*>(take((size_t(lf) + 1) * 4));
+          ws.scan_tmp = reinterpret_cast<uint32_t*>(take((size_t(lf) / 2048 + 2) * 4));
+          ws.step_state = reinterpret_cast<float4*>(take(size_t(lf) * mi::kBptStepF4 * 16));
+          ws.step_rays = reinterpret_cast<float4*>(take(size_t(lf) * 32));
+          ws.step_hits = reinterpret_cast<float4*>(take(size_t(lf) * 16));
+          ws.step_active[0] = reinterpret_cast<uint32_t*>(take(size_t(lf) * 4));
+          ws.step_active[1] = reinterpret_cast<uint32_t*>(take(size_t(lf) * 4));
+          ws.step_count = reinterpret_cast<uint32_t*>(take(1024));  // [0..1] list counts, [4..5] path cursors of the regenerating kernels, [8..71] chunk cursors of the walking waves
+        }
       }
     } else {
       rc = ensure(reinterpret_cast<void**>(&h->bpt_slab), &h->bpt_slab_bytes, size_t(lanes) * cap * 112);
@@ -1481,10 +1503,11 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
     else if (lanes > 256) lanes = (lanes / 2 + 255) / 256 * 256;
     else return rc;
   }
-  *lanes_per_launch = uint32_t(lanes);
+  if (!staged) lanes_flight = lanes;
+  *lanes_per_launch = uint32_t(lanes_flight);
   if (std::getenv("MI_BPT_DEBUG")) {
     size_t f = 0, t = 0; (void)hipMemGetInfo(&f, &t);
-    std::fprintf(stderr, "[mi_bpt] paths per launch %llu, vertices per sub-path %u, slab budget %.1f GB, device free %.1f of %.1f GB, arena %.1f GB\n", (unsigned long long)lanes,
+    std::fprintf(stderr, "[mi_bpt] %u launch(es) in flight, paths per launch %llu, vertices per sub-path %u, slab budget %.1f GB, device free %.1f of %.1f GB, arena %.1f GB\n", flights, (unsigned long long)lanes_flight,
                  w.max_vertices, double(budget) / 1073741824.0, double(f) / 1073741824.0, double(t) / 1073741824.0, double(h->bpt_arena_bytes) / 1073741824.0);
   }
   p.counters = h->d_counters;
@@ -1509,38 +1532,141 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
   HIP_TRY(hipSetDevice(h->device));
   mi::RenderParams p; mi::BptState w; uint32_t per_launch = 0;
   const uint64_t tiles_x = (uint64_t(win.w) + 7) / 8, tiles_y = (uint64_t(win.h) + 7) / 8, total = tiles_x * tiles_y * 64;
-  // lanes of a launch: up to 1 M paths over SEVERAL frames (r04: a launch of one 512 x 512 frame is 4 096 waves — one round of the chip, which then waits for
-  // its longest sub-path; with four frames per launch that tail overlaps the next waves' work)
-  int rc = bpt_prepare(h, camera_id, width, height, total * uint64_t(spp), p, w, &per_launch);
+  // r04 — LAUNCHES IN FLIGHT.  The tracing stage of a launch lasts as long as its longest sub-path (~140 vertices of dependent tree walks at roulette 0.9: 1.3 ms of
+  // a sub-path kernel however few lanes are left in it), and one launch is only a few paths per resident lane.  The paths of a "launch" are therefore dealt to
+  // launches on streams of their own (same arena, a share each); while one of them is in its tail another traces or connects.  Each keeps the order trace ->
+  // item count on the host -> connect; the frames of a batch are committed when all of its launches are done.  Measured (profiles/r04/ab_bpt_steps.txt #6): two
+  // in flight -5 .. -11 % (LivingRoomLit 188 -> 167 ms), MetalRings +6 %; four need more hardware queues than the runtime gives a process by default (two streams then
+  // share one: +15 %) and reach no more with GPU_MAX_HW_QUEUES=8 — overlapping kernels slow each other down, the chip was not idle through those tails, it was
+  // waiting on memory.  MI_BPT_FLIGHTS=1..4 (1: one launch at a time).
+  uint32_t flights = bpt_staged() ? 2u : 1u;
+  if (const char* e = std::getenv("MI_BPT_FLIGHTS")) { const int v = std::atoi(e); if (v >= 1 && v <= int(mi_pt_handle::kBptFlights)) flights = bpt_staged() ? uint32_t(v) : 1u; }
+  if (total * uint64_t(spp) < (1ull << 18)) flights = 1;  // nothing to overlap
+  mi::BptState wmore[mi_pt_handle::kBptFlights];
+  // lanes of a launch: up to 1 M paths over SEVERAL frames in flight (r04: a launch of one 512 x 512 frame is 4 096 waves — one round of the chip, which then waits for
+  // its longest sub-path)
+  int rc = bpt_prepare(h, camera_id, width, height, total * uint64_t(spp), p, w, &per_launch, flights, wmore);
   if (rc) return rc;
   p.win_x0 = win.x0; p.win_y0 = win.y0; p.win_w = win.w; p.win_h = win.h; p.tiles_x = uint32_t(tiles_x); p.tiles_y = uint32_t(tiles_y);
   p.spp = spp; p.seed = seed; p.sample_offset = sample_offset; p.n_chunks = 1;
   const size_t np = size_t(width) * height;
   rc = ensure(reinterpret_cast<void**>(&h->partial), &h->partial_bytes, np * 32); if (rc) return rc;
-  // frames are rendered in batches: each frame of a batch has its own eye / light image; the commit walks them in frame order
-  uint64_t batch = per_launch / total;
+  // frames are rendered in batches: each frame of a batch has its own eye / light image; the commit walks them in frame order.  A batch holds at least four
+  // rounds of the launches in flight (the pipeline drains at a commit) within 4 GB of images.
+  uint64_t batch = uint64_t(per_launch) * flights * (flights > 1 ? 16u : 1u) / total;
   if (batch < 1) batch = 1;
+  { const uint64_t by_mem = (4ull << 30) / (np * 36); if (batch > by_mem) batch = by_mem < 1 ? 1 : by_mem; }
   if (batch > spp) batch = spp;
   if (batch > 64) batch = 64;
   rc = ensure(reinterpret_cast<void**>(&h->bpt_eye), &h->bpt_eye_bytes, np * 12 * batch); if (rc) return rc;
   rc = ensure(reinterpret_cast<void**>(&h->bpt_light), &h->bpt_light_bytes, np * 24 * batch); if (rc) return rc;
   rc = ensure(reinterpret_cast<void**>(&h->d_rgbn), &h->rgbn_bytes, np * 16); if (rc) return rc;
   p.partial = h->partial; w.eye = h->bpt_eye; w.light = h->bpt_light;
+  for (uint32_t f = 1; f < flights; ++f) { wmore[f - 1].eye = w.eye; wmore[f - 1].light = w.light; }
   hipStream_t stream = h->stream;
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, mi::kCounterWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipMemsetAsync(h->partial, 0, np * 32, stream));
   HIP_TRY(hipMemsetAsync(h->bpt_eye, 0, np * 12 * batch, stream));
   HIP_TRY(hipMemsetAsync(h->bpt_light, 0, np * 24 * batch, stream));
   HIP_TRY(hipEventRecord(h->ev0, stream));
-  for (uint32_t f = 0; f < spp; f += uint32_t(batch)) {
-    w.frame = f; w.frames = uint32_t(spp - f < batch ? spp - f : batch);
-    const uint64_t lanes_total = total * w.frames;
-    for (uint64_t first = 0; first < lanes_total; first += per_launch) {
-      w.first = uint32_t(first); w.lanes = uint32_t(lanes_total - first < per_launch ? lanes_total - first : per_launch);
-      rc = bpt_launch(h, p, w, false, stream);
-      if (rc) return rc;
+  if (flights <= 1) {
+    for (uint32_t f = 0; f < spp; f += uint32_t(batch)) {
+      w.frame = f; w.frames = uint32_t(spp - f < batch ? spp - f : batch);
+      const uint64_t lanes_total = total * w.frames;
+      for (uint64_t first = 0; first < lanes_total; first += per_launch) {
+        w.first = uint32_t(first); w.lanes = uint32_t(lanes_total - first < per_launch ? lanes_total - first : per_launch);
+        rc = bpt_launch(h, p, w, false, stream);
+        if (rc) return rc;
+      }
+      HIP_TRY(mi::bpt_launchers(p.features).commit(p, w, stream));
     }
-    HIP_TRY(mi::bpt_launchers(p.features).commit(p, w, stream));
+  } else {
+    const mi::BptLaunchers bl = mi::bpt_launchers(p.features);
+    const bool lds = use_lds_scene(h) && h->stack_fits_lds;
+    if (!h->bpt_pinned) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bpt_pinned), sizeof(unsigned long long) * 2 * mi_pt_handle::kBptFlights, hipHostMallocDefault));
+    if (!h->bpt_fork) HIP_TRY(hipEventCreateWithFlags(&h->bpt_fork, hipEventDisableTiming));
+    for (uint32_t f = 0; f < flights; ++f) {
+      auto& fl = h->bpt_flight[f];
+      if (!fl.stream) HIP_TRY(hipStreamCreateWithFlags(&fl.stream, hipStreamNonBlocking));
+      if (!fl.done) HIP_TRY(hipEventCreateWithFlags(&fl.done, hipEventDisableTiming));
+    }
+    const bool debug = std::getenv("MI_BPT_DEBUG") != nullptr;
+    mi::BptState cur[mi_pt_handle::kBptFlights];
+    bool pending[mi_pt_handle::kBptFlights] = {false, false, false, false};
+    auto state_of = [&](uint32_t f) -> mi::BptState& { return f == 0 ? w : wmore[f - 1]; };
+    auto begin = [&](uint32_t f, uint32_t frame, uint32_t frames, uint64_t first, uint32_t lanes) -> int {
+      auto& fl = h->bpt_flight[f];
+      mi::BptState ws = state_of(f);
+      ws.frame = frame; ws.frames = frames; ws.first = uint32_t(first); ws.lanes = lanes; ws.async_total = 1u;
+      uint32_t* total_word = reinterpret_cast<uint32_t*>(h->bpt_pinned + 2 * f);
+      HIP_TRY(bl.trace(p, ws, false, lds, fl.stream, total_word));
+      HIP_TRY(hipMemcpyAsync(h->bpt_pinned + 2 * f + 1, h->d_counters + 15, sizeof(unsigned long long), hipMemcpyDeviceToHost, fl.stream));
+      cur[f] = ws; pending[f] = true;
+      return MI_OK;
+    };
+    // a sub-path outgrew its slab share in one of the traces in flight (the counter does not say which): none of them has been connected yet — wait for all,
+    // and redo each through the one-at-a-time path, which slices it at a larger share (bpt_launch)
+    auto redo_pending = [&]() -> int {
+      for (uint32_t g = 0; g < flights; ++g) if (pending[g]) HIP_TRY(hipStreamSynchronize(h->bpt_flight[g].stream));
+      HIP_TRY(hipMemset(h->d_counters + 15, 0, sizeof(unsigned long long)));
+      for (uint32_t g = 0; g < flights; ++g) {
+        if (!pending[g]) continue;
+        mi::BptState ws = cur[g]; ws.async_total = 0u;
+        if (debug) std::fprintf(stderr, "[mi_bpt] launch in flight %u (%u paths) redone one at a time after an overflow\n", g, ws.lanes);
+        const int r = bpt_launch(h, p, ws, false, h->bpt_flight[g].stream);
+        if (r) return r;
+        pending[g] = false;
+      }
+      return MI_OK;
+    };
+    auto finish = [&](uint32_t f) -> int {
+      auto& fl = h->bpt_flight[f];
+      HIP_TRY(hipStreamSynchronize(fl.stream));
+      if (h->bpt_pinned[2 * f + 1] != 0ull) return redo_pending();
+      const uint32_t items = *reinterpret_cast<const uint32_t*>(h->bpt_pinned + 2 * f);
+      mi::BptState& ws = cur[f];
+      ws.dyn_vis = (!lds && items >= (2u << 20) / flights) ? 1u : 0u;  // the rule of bpt_launch at this launch's share of the paths
+      if (const char* e = std::getenv("MI_BPT_DYN_VIS")) ws.dyn_vis = std::atoi(e) != 0 ? 1u : 0u;
+      const size_t n_it = items ? items : 1, occl_bytes = ws.dyn_vis ? (n_it + 255) / 256 * 256 : 0;
+      const size_t values_need = n_it * (ws.dyn_vis ? 48 : 16) + occl_bytes + 256;
+      if (fl.values_bytes < values_need) { const int r = ensure(reinterpret_cast<void**>(&fl.values), &fl.values_bytes, values_need + values_need / 4); if (r) return r; }
+      ws.values = fl.values;
+      ws.rays = ws.dyn_vis ? fl.values + n_it : nullptr;
+      ws.occl = ws.dyn_vis ? reinterpret_cast<uint8_t*>(fl.values + 3 * n_it) : nullptr;
+      ws.pool = ws.dyn_vis ? reinterpret_cast<uint32_t*>(ws.occl + occl_bytes) : nullptr;
+      ws.vis_th = 16u; ws.vis_wide = p.wide_nodes == 1u ? 1u : 0u;
+      if (const char* e = std::getenv("MI_BPT_VIS_TH")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ws.vis_th = uint32_t(v); }
+      if (const char* e = std::getenv("MI_BPT_VIS_WIDE")) ws.vis_wide = std::atoi(e) != 0 ? 1u : 0u;
+      HIP_TRY(bl.connect(p, ws, false, lds, items, fl.stream));
+      pending[f] = false;
+      return MI_OK;
+    };
+    h->bpt_step_rounds = 0;
+    uint64_t k = 0;  // launches begun so far: launch k runs on flight k mod flights
+    for (uint32_t f0 = 0; f0 < spp; f0 += uint32_t(batch)) {
+      const uint32_t frames = uint32_t(spp - f0 < batch ? spp - f0 : batch);
+      const uint64_t lanes_total = total * frames;
+      HIP_TRY(hipEventRecord(h->bpt_fork, stream));  // the images are cleared (first batch) or committed (later ones)
+      for (uint32_t f = 0; f < flights; ++f) HIP_TRY(hipStreamWaitEvent(h->bpt_flight[f].stream, h->bpt_fork, 0));
+      for (uint64_t first = 0; first < lanes_total; ++k) {
+        const uint32_t f = uint32_t(k % flights);
+        const uint32_t lanes = uint32_t(lanes_total - first < per_launch ? lanes_total - first : per_launch);
+        if (pending[f]) { rc = finish(f); if (rc) return rc; }
+        rc = begin(f, f0, frames, first, lanes);
+        if (rc) return rc;
+        first += lanes;
+      }
+      for (uint32_t j = 0; j < flights; ++j) {  // drain in the order the launches were begun
+        const uint32_t f = uint32_t((k + j) % flights);
+        if (pending[f]) { rc = finish(f); if (rc) return rc; }
+      }
+      for (uint32_t f = 0; f < flights; ++f) {
+        HIP_TRY(hipEventRecord(h->bpt_flight[f].done, h->bpt_flight[f].stream));
+        HIP_TRY(hipStreamWaitEvent(stream, h->bpt_flight[f].done, 0));
+      }
+      w.frame = f0; w.frames = frames;
+      HIP_TRY(bl.commit(p, w, stream));
+    }
   }
   HIP_TRY(hipEventRecord(h->ev1, stream));
   HIP_TRY(mi::launch_finalize(h->partial, h->d_rgbn, width, height, win.x0, win.y0, win.w, win.h, 1, stream));

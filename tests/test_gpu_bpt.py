@@ -210,6 +210,36 @@ def test_bpt_tracing_stage_with_path_regeneration_is_bit_identical_per_path(monk
         assert np.array_equal(np.asarray(b[2])[:3000], np.asarray(o[2])) and _bits_equal(b[0][:3000], o[0]).all() and _bits_equal(b[1][:3000], o[1]).all()
 
 
+@pytest.mark.parametrize("name", ["CornellBoxSpecular", "LivingRoomLit"])
+def test_bpt_launches_in_flight_render_the_same_image(monkeypatch, name):
+    """r04: mi_bpt_render deals the paths of a launch to launches in flight on streams of their own (trace -> item count -> connect each; one commit per
+    batch of frames).  Every path is what it is whichever launch holds it: denominators equal, sums equal up to the free FP64 order of the splats."""
+    s = load_scene(name)
+    pt = ma.PathTracing(s, beta=2.0)
+    imgs = []
+    for fl in ("1", "2", "4"):
+        monkeypatch.setenv("MI_BPT_FLIGHTS", fl)
+        imgs.append(pt.bpt_render_rgbn(256, 192, spp=12, seed=4))  # 590 k paths: several launches per flight
+        assert pt.last_stats.num_paths == 256 * 192 * 12
+    for b in imgs[1:]:
+        assert np.array_equal(imgs[0][..., 3], b[..., 3])
+        np.testing.assert_allclose(imgs[0], b, rtol=2e-6, atol=1e-12)
+
+
+def test_bpt_overflow_while_launches_are_in_flight(monkeypatch):
+    """a sub-path that outgrows its slab share while two launches are in flight: the shared counter does not say whose it was — every trace not yet connected
+    is redone one at a time in slices at a larger share (bpt_launch).  Closed furnace at roulette 0.97 (sub-paths of a hundred vertices) with a slab budget
+    that leaves 16 vertices: the image equals the one rendered with room for every path."""
+    s = load_scene("TestCaseFurnace")
+    pt = ma.PathTracing(s, beta=2.0, roulette=0.97)
+    monkeypatch.setenv("MI_BPT_FLIGHTS", "2")
+    ref = pt.bpt_render_rgbn(256, 256, spp=5, seed=11)
+    monkeypatch.setenv("MI_BPT_SLAB_MB", "64")
+    a = pt.bpt_render_rgbn(256, 256, spp=5, seed=11)
+    assert np.array_equal(ref[..., 3], a[..., 3])
+    np.testing.assert_allclose(ref, a, rtol=2e-6, atol=1e-12)
+
+
 def test_bpt_visibility_stage_against_the_oracle(monkeypatch):
     """the forced visibility stage against the CPU oracle directly (not only against the other device form)"""
     monkeypatch.setenv("MI_BPT_DYN_VIS", "1")

@@ -15,6 +15,10 @@ struct BptState {
   uint32_t frame;          // image mode: sample index of the first frame of this batch (added to RenderParams::sample_offset)
   uint32_t frames;         // image mode: frames in this batch (each with its own eye / light image)
   uint32_t max_vertices;   // capacity of a lane's light sub-path (BPT.hpp:30 allows 1024)
+  const uint32_t* path_ids;  // image mode: lane i holds path path_ids[i] of the batch instead of first + i (the launch of the paths that outgrew their slab share)
+  uint32_t* over_ids;      // image mode, r04: a path whose sub-path outgrows max_vertices is set aside — its index (first + i) is appended here, it contributes nothing
+  uint32_t* over_count;    // in this launch — and is traced again at the reference's capacity when the batch's launches are done.  nullptr: the launch counts
+                           // the overflow (counters[15]) and the host redoes it in slices
   uint32_t async_total;    // 1: bpt_stage_trace leaves the item count's copy to the (pinned) host word in flight instead of waiting for it (launches overlapped on several streams)
   float4* slab;            // one-kernel form: [max_vertices][7][lanes] light sub-path vertices
   // staged form: path-major records (7 float4 per vertex), emission terms, per-path info, item offsets and values

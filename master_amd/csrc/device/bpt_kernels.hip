@@ -465,7 +465,7 @@ MI_DEV Lane lane_decode(const RenderParams& p, const BptState& w, uint32_t i) {
     if (l.ok) { l.px = p.list_xy[2 * item]; l.py = p.list_xy[2 * item + 1]; l.sample = p.list_sample[item]; }
   } else {
     const uint32_t per_frame = p.tiles_x * p.tiles_y * 64u;
-    const uint32_t gi = w.first + i;
+    const uint32_t gi = w.path_ids ? (i < w.lanes ? w.path_ids[i] : 0u) : w.first + i;
     l.fl = gi / per_frame;
     const uint32_t rem = gi - l.fl * per_frame, tile = rem >> 6, pix = rem & 63u;
     const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
@@ -482,6 +482,14 @@ MI_DEV void ctx_init(Ctx& c, const RenderParams& p, const BptState& w, void* sta
   c.sphere_c = F3(w.sphere[0], w.sphere[1], w.sphere[2]); c.sphere_r = w.sphere[3];
   c.sky_horizon = F3(w.sky_horizon[0], w.sky_horizon[1], w.sky_horizon[2]); c.sky_zenith = F3(w.sky_zenith[0], w.sky_zenith[1], w.sky_zenith[2]);
   c.n_basic = 0; c.n_shadow = 0;
+}
+
+// a sub-path outgrew the slab share: set the path aside for the batch's launch at the reference's capacity (BptState::over_ids), or count it for the host
+MI_DEV bool set_aside(const BptState& w, uint32_t i, bool& overflow) {
+  if (!w.over_ids) { overflow = true; return false; }
+  const uint32_t slot = atomicAdd(w.over_count, 1u);
+  w.over_ids[slot] = w.path_ids ? w.path_ids[i] : w.first + i;  // the list holds every path of the batch (host): no bound to test
+  return true;
 }
 
 }  // namespace
@@ -515,6 +523,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace(const RenderParams p,
   bool overflow = false;
   if (i < w.lanes) {
     uint32_t L = 0, E = 0, n_items = 0, n_em = 0, n_dir = 0, basic = 0;
+    bool aside = false;
     if (ln.ok) {
       Ctx c; ctx_init(c, p, w, &stack, sb, &sv);
       const m33 v2w = {F3(p.v2w[0], p.v2w[1], p.v2w[2]), F3(p.v2w[3], p.v2w[4], p.v2w[5]), F3(p.v2w[6], p.v2w[7], p.v2w[8])};
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace(const RenderParams p,
             const BSample b = bpt_bsdf_sample(c, g, prev.surface, prev.omega);
             const Surf surface = scene_intersect<QN>(c, prev.surface, b.omega, 1u << MI_ENTITY_MESH);
             if (surface.material_id == 0xFFFFFFFFu) break;
-            if (size >= w.max_vertices) { overflow = true; break; }
+            if (size >= w.max_vertices) { aside = set_aside(w, i, overflow); break; }
             LVert cur;
             cur.surface = surface;
             cur.omega = -b.omega;
@@ -568,9 +577,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace(const RenderParams p,
         Surf surface = cs;
         prev.surface = surface; prev.omega = -dir; prev.throughput = F3(1, 1, 1) * c.rinv;
         prev.finite = 1; prev.c = 0.0f; prev.C = 0.0f;
-        for (;;) {
+        if (!aside) for (;;) {
           const bool at_camera = (prev.surface.material_id & 3u) == MI_ENTITY_CAMERA;
-          if (E >= w.max_vertices) { overflow = true; break; }
+          if (E >= w.max_vertices) { aside = set_aside(w, i, overflow); break; }
           if (at_camera) {
             rec_store_e(erec + size_t(E) * 7u, prev, 0u, 0u);  // items [0, L): the splats of _connect_eye
             evi[E] = make_uint2(0u, 0u);
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace(const RenderParams p,
             cur.C = (prev.C * betaf(c, b.q.densityRev) + prev.c * float(prev.finite)) * betaf(c, e.bG) * cur.c;
             if (surf_is_light(surface)) {
               const f3 t = bpt_connect_light(c, cur);
-              if (n_em >= w.max_vertices) { overflow = true; ended = true; break; }
+              if (n_em >= w.max_vertices) { aside = set_aside(w, i, overflow); ended = true; break; }
               em[n_em++] = make_float4(t.x, t.y, t.z, __uint_as_float(k));
             } else break;
           }
@@ -622,8 +631,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace(const RenderParams p,
       }
       basic = c.n_basic;
     }
+    if (aside) { L = E = n_items = n_em = n_dir = basic = 0u; }  // set aside: nothing of it counts in this launch
     w.info[2 * size_t(i)] = make_uint4(L, E, n_items, n_em);
-    w.info[2 * size_t(i) + 1] = make_uint4(basic, n_dir, (ln.py << 16) | ln.px, (ln.fl << 1) | (ln.ok ? 1u : 0u));
+    w.info[2 * size_t(i) + 1] = make_uint4(basic, n_dir, (ln.py << 16) | ln.px, (ln.fl << 1) | (ln.ok && !aside ? 1u : 0u));
     w.item_offset[i] = n_items;
   }
   uint32_t o = overflow ? 1u : 0u;
@@ -706,7 +716,10 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace_light(const RenderPar
         const BSample b = bpt_bsdf_sample(c, g, prev.surface, prev.omega);
         const Surf surface = scene_intersect<QN>(c, prev.surface, b.omega, 1u << MI_ENTITY_MESH);
         if (surface.material_id == 0xFFFFFFFFu) ending = true;
-        else if (size >= w.max_vertices) { overflow = true; ending = true; }
+        else if (size >= w.max_vertices) {
+          if (set_aside(w, i, overflow)) { w.info[2 * size_t(i)] = make_uint4(0u, 0u, 0u, 2u); alive = false; }  // 2: bpt_trace_eye leaves the path alone
+          else ending = true;
+        }
         else {
           LVert cur;
           cur.surface = surface;
@@ -776,6 +789,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace_eye(const RenderParam
           pxy = (ln.py << 16) | ln.px; flk = (ln.fl << 1) | (ln.ok ? 1u : 0u);
           uint4 res = make_uint4(0u, 0u, 0u, 0u);
           if (ln.ok) res = w.info[2 * size_t(i)];
+          if (res.w == 2u) { res.w = 0u; flk &= ~1u; }  // set aside by bpt_trace_light
           if (res.w != 0u) {
             g = rng_seed(p.seed, ln.py * p.width + ln.px, ln.sample);
             const float u0 = rng_f(g), u1 = rng_f(g);
@@ -802,8 +816,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace_eye(const RenderParam
       float4* nrec = w.nslab + size_t(i) * w.max_vertices * 7u;
       float4* em = w.emission + size_t(i) * w.max_vertices;
       uint2* evi = w.evinfo + size_t(i) * w.max_vertices;
-      bool ended = false;
-      if (E >= w.max_vertices) { overflow = true; ended = true; }
+      bool ended = false, aside = false;
+      if (E >= w.max_vertices) { aside = set_aside(w, i, overflow); ended = true; }
       else {
         const bool at_camera = (prev.surface.material_id & 3u) == MI_ENTITY_CAMERA;
         if (at_camera) {
@@ -846,7 +860,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace_eye(const RenderParam
           cur.C = (prev.C * betaf(c, b.q.densityRev) + prev.c * float(prev.finite)) * betaf(c, e.bG) * cur.c;
           if (surf_is_light(surface)) {
             const f3 t = bpt_connect_light(c, cur);
-            if (n_em >= w.max_vertices) { overflow = true; ended = true; break; }
+            if (n_em >= w.max_vertices) { aside = set_aside(w, i, overflow); ended = true; break; }
             em[n_em++] = make_float4(t.x, t.y, t.z, __uint_as_float(k));
           } else break;
         }
@@ -857,6 +871,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void bpt_trace_eye(const RenderParam
         }
       }
       if (ended) {
+        if (aside) { L = E = n_items = n_em = n_dir = 0u; c.n_basic = 0u; flk &= ~1u; }  // set aside: nothing of it counts in this launch
         w.info[2 * size_t(i)] = make_uint4(L, E, n_items, n_em);
         w.info[2 * size_t(i) + 1] = make_uint4(c.n_basic, n_dir, pxy, flk);
         w.item_offset[i] = n_items;

@@ -77,6 +77,7 @@ struct mi_pt_handle {
   struct BptFlight { hipStream_t stream = nullptr; hipEvent_t done = nullptr; float4* values = nullptr; size_t values_bytes = 0; };
   BptFlight bpt_flight[kBptFlights];
   unsigned long long* bpt_pinned = nullptr;  // [kBptFlights][2]
+  uint32_t* bpt_aside = nullptr; size_t bpt_aside_bytes = 0;  // [0] count, [16 ..] indices of the batch's paths set aside for the launch at 1024 vertices
   hipEvent_t bpt_fork = nullptr;             // h->stream -> the flights' streams
   float* bpt_eye = nullptr; size_t bpt_eye_bytes = 0;
   double* bpt_light = nullptr; size_t bpt_light_bytes = 0;
@@ -611,6 +612,7 @@ void mi_pt_destroy(mi_pt_handle* h) {
     if (fl.stream) D(hipStreamDestroy(fl.stream));
   }
   if (h->bpt_pinned) D(hipHostFree(h->bpt_pinned));
+  if (h->bpt_aside) D(hipFree(h->bpt_aside));
   if (h->bpt_fork) D(hipEventDestroy(h->bpt_fork));
   if (h->bpt_eye) D(hipFree(h->bpt_eye));
   if (h->bpt_light) D(hipFree(h->bpt_light));
@@ -1403,7 +1405,7 @@ int bpt_launch(mi_pt_handle* h, const mi::RenderParams& p, mi::BptState& w, bool
 // buffers and per-launch constants shared by the two BPT entry points
 // flights > 1 (mi_bpt_render): the launch's paths and the arena are dealt to `flights` launches in flight; w is the first one's state, more[0 .. flights - 2] the others'
 int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t height, uint64_t total_lanes, mi::RenderParams& p, mi::BptState& w,
-                uint32_t* lanes_per_launch, uint32_t flights = 1, mi::BptState* more = nullptr) {
+                uint32_t* lanes_per_launch, uint32_t flights = 1, mi::BptState* more = nullptr, bool set_aside = false) {
   std::memset(&p, 0, sizeof p); std::memset(&w, 0, sizeof w);
   int rc = fill_camera(h, camera_id, width, height, p);
   if (rc) return rc;
@@ -1427,7 +1429,9 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   std::memcpy(w.sky_horizon, h->sky_horizon, sizeof w.sky_horizon); std::memcpy(w.sky_zenith, h->sky_zenith, sizeof w.sky_zenith);
   if (width > 65535u || height > 65535u)  // the staged form packs a path's pixel as (y << 16) | x in its info record (bpt_kernels.hip)
     return fail(MI_ERR_UNSUPPORTED, "BPT: width and height must not exceed 65535");
-  uint64_t max_lanes = 1ull << 20;  // up to 1 M paths per launch (MI_BPT_LANES_LOG2 = 16 .. 22: measurement)
+  // up to 1 M paths per launch (MI_BPT_LANES_LOG2 = 16 .. 22: measurement); 4 M where a path that outgrows its slab share is set aside for a launch of its own
+  // (mi_bpt_render, r04): the share may then be short — 80 vertices hold all but 0.02 % of the sub-paths at roulette 0.9 — and the same slabs hold four times the paths
+  uint64_t max_lanes = set_aside ? (1ull << 22) : (1ull << 20);
   if (const char* e = std::getenv("MI_BPT_LANES_LOG2")) { const int v = std::atoi(e); if (v >= 16 && v <= 22) max_lanes = 1ull << v; }
   uint64_t lanes = total_lanes < max_lanes ? total_lanes : max_lanes;
   lanes = (lanes + 255) / 256 * 256;
@@ -1459,7 +1463,7 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
   uint64_t cap = budget / (lanes * 112ull);
   // little memory (another handle or process holds the device): fewer paths per launch before a short slab — a sub-path of more than 192 vertices is a 2e-9
   // event at roulette 0.9, one of more than 80 happens in every launch, and an overflowing launch is redone in slices (bpt_launch)
-  while (cap < 192 && lanes > (1ull << 18)) { lanes = (lanes / 2 + 255) / 256 * 256; cap = budget / (lanes * 112ull); }
+  while (cap < (set_aside ? 64u : 192u) && lanes > (1ull << 18)) { lanes = (lanes / 2 + 255) / 256 * 256; cap = budget / (lanes * 112ull); }
   if (cap > 1024) cap = 1024;
   if (cap < 16) cap = 16;
   uint64_t lanes_flight = lanes;
@@ -1471,7 +1475,9 @@ int bpt_prepare(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t he
       const size_t slab = size_t(lf) * cap * 112;
       const size_t step_bytes = size_t(lf) * (mi::kBptStepF4 * 16 + 32 + 16 + 8) + 4096;  // tracing stage as uniform steps: state, ray, hit, two index lists per path
       const size_t need = (3 * slab + size_t(lf) * (cap * 24 + 32 + 4 + 1) + 16384 + step_bytes) * flights;
-      rc = ensure(reinterpret_cast<void**>(&h->bpt_arena), &h->bpt_arena_bytes, need);
+      // a little more than asked: the per-path arrays make the need move by a per cent with the split into paths x vertices, and growing the arena means waiting for
+      // the driver to take back ~100 GB first (seconds)
+      rc = h->bpt_arena_bytes >= need ? MI_OK : ensure(reinterpret_cast<void**>(&h->bpt_arena), &h->bpt_arena_bytes, need + need / 32);
       if (rc == MI_OK) {
         char* a = h->bpt_arena;
         auto take = [&](size_t bytes) { char* r = a; a += (bytes + 255) / 256 * 256; return r; };
@@ -1545,7 +1551,8 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
   mi::BptState wmore[mi_pt_handle::kBptFlights];
   // lanes of a launch: up to 1 M paths over SEVERAL frames in flight (r04: a launch of one 512 x 512 frame is 4 096 waves — one round of the chip, which then waits for
   // its longest sub-path)
-  int rc = bpt_prepare(h, camera_id, width, height, total * uint64_t(spp), p, w, &per_launch, flights, wmore);
+  const bool aside = bpt_staged() && !(std::getenv("MI_BPT_SET_ASIDE") && std::atoi(std::getenv("MI_BPT_SET_ASIDE")) == 0);
+  int rc = bpt_prepare(h, camera_id, width, height, total * uint64_t(spp), p, w, &per_launch, flights, wmore, aside);
   if (rc) return rc;
   p.win_x0 = win.x0; p.win_y0 = win.y0; p.win_w = win.w; p.win_h = win.h; p.tiles_x = uint32_t(tiles_x); p.tiles_y = uint32_t(tiles_y);
   p.spp = spp; p.seed = seed; p.sample_offset = sample_offset; p.n_chunks = 1;
@@ -1556,13 +1563,39 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
   uint64_t batch = uint64_t(per_launch) * flights * (flights > 1 ? 16u : 1u) / total;
   if (batch < 1) batch = 1;
   { const uint64_t by_mem = (4ull << 30) / (np * 36); if (batch > by_mem) batch = by_mem < 1 ? 1 : by_mem; }
+  if (aside) { const uint64_t by_ids = (1ull << 28) / total; if (batch > by_ids) batch = by_ids < 1 ? 1 : by_ids; }  // the list of paths set aside holds every path of a batch: <= 1 GB
   if (batch > spp) batch = spp;
   if (batch > 64) batch = 64;
   rc = ensure(reinterpret_cast<void**>(&h->bpt_eye), &h->bpt_eye_bytes, np * 12 * batch); if (rc) return rc;
   rc = ensure(reinterpret_cast<void**>(&h->bpt_light), &h->bpt_light_bytes, np * 24 * batch); if (rc) return rc;
   rc = ensure(reinterpret_cast<void**>(&h->d_rgbn), &h->rgbn_bytes, np * 16); if (rc) return rc;
   p.partial = h->partial; w.eye = h->bpt_eye; w.light = h->bpt_light;
-  for (uint32_t f = 1; f < flights; ++f) { wmore[f - 1].eye = w.eye; wmore[f - 1].light = w.light; }
+  if (aside) {
+    const uint64_t ids = total * (batch < spp ? batch : uint64_t(spp));
+    rc = ensure(reinterpret_cast<void**>(&h->bpt_aside), &h->bpt_aside_bytes, (ids + 16) * 4); if (rc) return rc;
+    w.over_count = h->bpt_aside; w.over_ids = h->bpt_aside + 16;
+  }
+  for (uint32_t f = 1; f < flights; ++f) { wmore[f - 1].eye = w.eye; wmore[f - 1].light = w.light; wmore[f - 1].over_count = w.over_count; wmore[f - 1].over_ids = w.over_ids; }
+  // the paths of a batch that outgrew their slab share, traced again at the reference's capacity of 1024 vertices (BPT.hpp:30) through the first launch's arena,
+  // which holds share / 1024 of its paths at that capacity; `on` = the stream that arena's work is ordered on.  Called when every trace of the batch is done.
+  auto flush_aside = [&](uint32_t f0, uint32_t frames, hipStream_t on) -> int {
+    if (!aside) return MI_OK;
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, h->bpt_aside, sizeof n, hipMemcpyDeviceToHost));
+    if (n == 0) return MI_OK;
+    if (std::getenv("MI_BPT_DEBUG")) std::fprintf(stderr, "[mi_bpt] %u paths of the batch outgrew %u vertices: traced again at 1024\n", n, w.max_vertices);
+    if (w.max_vertices >= 1024u) return fail(MI_ERR_UNSUPPORTED, "BPT: a sub-path exceeds 1024 vertices (the reference's fixed_vector capacity)");
+    const uint64_t chunk = uint64_t(per_launch) * w.max_vertices / 1024u;
+    if (chunk == 0) return fail(MI_ERR_UNSUPPORTED, "BPT: a sub-path exceeds the vertex slab of a single path");
+    for (uint64_t done = 0; done < n; done += chunk) {
+      mi::BptState wm = w;
+      wm.frame = f0; wm.frames = frames; wm.first = 0; wm.lanes = uint32_t(n - done < chunk ? n - done : chunk); wm.max_vertices = 1024u;
+      wm.path_ids = h->bpt_aside + 16 + done; wm.over_ids = nullptr; wm.over_count = nullptr; wm.async_total = 0u;
+      const int r = bpt_launch(h, p, wm, false, on);
+      if (r) return r;
+    }
+    return MI_OK;
+  };
   hipStream_t stream = h->stream;
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, mi::kCounterWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipMemsetAsync(h->partial, 0, np * 32, stream));
@@ -1573,11 +1606,14 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
     for (uint32_t f = 0; f < spp; f += uint32_t(batch)) {
       w.frame = f; w.frames = uint32_t(spp - f < batch ? spp - f : batch);
       const uint64_t lanes_total = total * w.frames;
+      if (aside) HIP_TRY(hipMemsetAsync(h->bpt_aside, 0, 64, stream));
       for (uint64_t first = 0; first < lanes_total; first += per_launch) {
         w.first = uint32_t(first); w.lanes = uint32_t(lanes_total - first < per_launch ? lanes_total - first : per_launch);
         rc = bpt_launch(h, p, w, false, stream);
         if (rc) return rc;
       }
+      rc = flush_aside(f, w.frames, stream);
+      if (rc) return rc;
       HIP_TRY(mi::bpt_launchers(p.features).commit(p, w, stream));
     }
   } else {
@@ -1625,7 +1661,7 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
       if (h->bpt_pinned[2 * f + 1] != 0ull) return redo_pending();
       const uint32_t items = *reinterpret_cast<const uint32_t*>(h->bpt_pinned + 2 * f);
       mi::BptState& ws = cur[f];
-      ws.dyn_vis = (!lds && items >= (2u << 20) / flights) ? 1u : 0u;  // the rule of bpt_launch at this launch's share of the paths
+      ws.dyn_vis = (!lds && items >= (1u << 19) && uint64_t(items) >= 2ull * ws.lanes) ? 1u : 0u;  // the rule of bpt_launch (2 M items for 1 M paths) per path
       if (const char* e = std::getenv("MI_BPT_DYN_VIS")) ws.dyn_vis = std::atoi(e) != 0 ? 1u : 0u;
       const size_t n_it = items ? items : 1, occl_bytes = ws.dyn_vis ? (n_it + 255) / 256 * 256 : 0;
       const size_t values_need = n_it * (ws.dyn_vis ? 48 : 16) + occl_bytes + 256;
@@ -1646,6 +1682,7 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
     for (uint32_t f0 = 0; f0 < spp; f0 += uint32_t(batch)) {
       const uint32_t frames = uint32_t(spp - f0 < batch ? spp - f0 : batch);
       const uint64_t lanes_total = total * frames;
+      if (aside) HIP_TRY(hipMemsetAsync(h->bpt_aside, 0, 64, stream));
       HIP_TRY(hipEventRecord(h->bpt_fork, stream));  // the images are cleared (first batch) or committed (later ones)
       for (uint32_t f = 0; f < flights; ++f) HIP_TRY(hipStreamWaitEvent(h->bpt_flight[f].stream, h->bpt_fork, 0));
       for (uint64_t first = 0; first < lanes_total; ++k) {
@@ -1660,6 +1697,8 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
         const uint32_t f = uint32_t((k + j) % flights);
         if (pending[f]) { rc = finish(f); if (rc) return rc; }
       }
+      rc = flush_aside(f0, frames, h->bpt_flight[0].stream);
+      if (rc) return rc;
       for (uint32_t f = 0; f < flights; ++f) {
         HIP_TRY(hipEventRecord(h->bpt_flight[f].done, h->bpt_flight[f].stream));
         HIP_TRY(hipStreamWaitEvent(stream, h->bpt_flight[f].done, 0));

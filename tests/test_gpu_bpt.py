@@ -240,6 +240,26 @@ def test_bpt_overflow_while_launches_are_in_flight(monkeypatch):
     np.testing.assert_allclose(ref, a, rtol=2e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("name,slab_mb", [("CornellBoxSpecular", "600"), ("LivingRoomLit", "")])
+def test_bpt_paths_set_aside_for_the_launch_at_full_capacity(monkeypatch, name, slab_mb):
+    """r04: a path whose sub-path outgrows the slab share of its launch is set aside (its index appended to a list, nothing of it counted) and traced again,
+    with the others of its batch of frames, in a launch at the reference's 1024 vertices (BPT.hpp:30) before the frames are committed — so the share can be short
+    (80 vertices hold all but 0.02 % of the sub-paths at roulette 0.9) and a launch holds four times the paths.  Same image as with every launch redone in
+    slices (MI_BPT_SET_ASIDE=0): with a 600 MB budget (20 vertices: one path in eight is set aside) and at the default size."""
+    s = load_scene(name)
+    pt = ma.PathTracing(s, beta=2.0)
+    if slab_mb: monkeypatch.setenv("MI_BPT_SLAB_MB", slab_mb)
+    monkeypatch.setenv("MI_BPT_SET_ASIDE", "0")
+    a = pt.bpt_render_rgbn(256, 192, spp=12, seed=9)
+    st_a = pt.last_stats
+    monkeypatch.setenv("MI_BPT_SET_ASIDE", "1")
+    b = pt.bpt_render_rgbn(256, 192, spp=12, seed=9)
+    st_b = pt.last_stats
+    assert np.array_equal(a[..., 3], b[..., 3])
+    np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-12)
+    assert (st_a.num_paths, st_a.num_basic_rays, st_a.num_shadow_rays) == (st_b.num_paths, st_b.num_basic_rays, st_b.num_shadow_rays)
+
+
 def test_bpt_visibility_stage_against_the_oracle(monkeypatch):
     """the forced visibility stage against the CPU oracle directly (not only against the other device form)"""
     monkeypatch.setenv("MI_BPT_DYN_VIS", "1")

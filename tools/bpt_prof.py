@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import master_amd as ma
 s = ma.Scene.load(os.path.join(ROOT, "scenes", (sys.argv[1] if len(sys.argv) > 1 else "CornellBoxDiffuse") + ".miscene"))
 pt = ma.PathTracing(s, beta=2.0)
-pt.bpt_render_rgbn(512, 512, spp=4, seed=1)
+pt.bpt_render_rgbn(512, 512, spp=64, seed=1)
 pt.bpt_render_rgbn(512, 512, spp=64, seed=1)
 st = pt.last_stats
 print("%.1f ms, %.0f Mrays/s" % (st.trace_ms, (st.num_basic_rays + st.num_shadow_rays) / st.trace_ms / 1e3))

@@ -5,7 +5,8 @@ import master_amd as ma
 for name in sys.argv[1:]:
     s = ma.Scene.load(os.path.join(ROOT, "scenes", name + ".miscene"))
     pt = ma.PathTracing(s, beta=2.0)
-    pt.bpt_render_rgbn(512, 512, spp=8, seed=1)  # two launches: buffers at their working size before the timed call
+    pt.bpt_render_rgbn(512, 512, spp=64, seed=1)  # the same call once before it is timed: every buffer at its working size (an allocation that follows the
+    # destruction of the previous model's 116 GB arena waits seconds for the driver, profiles/r04/ab_bpt_steps.txt #5)
     t0 = time.perf_counter()
     pt.bpt_render_rgbn(512, 512, spp=64, seed=1)
     dt = time.perf_counter() - t0

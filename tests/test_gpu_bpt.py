@@ -226,13 +226,15 @@ def test_bpt_launches_in_flight_render_the_same_image(monkeypatch, name):
         np.testing.assert_allclose(imgs[0], b, rtol=2e-6, atol=1e-12)
 
 
-def test_bpt_overflow_while_launches_are_in_flight(monkeypatch):
-    """a sub-path that outgrows its slab share while two launches are in flight: the shared counter does not say whose it was — every trace not yet connected
-    is redone one at a time in slices at a larger share (bpt_launch).  Closed furnace at roulette 0.97 (sub-paths of a hundred vertices) with a slab budget
-    that leaves 16 vertices: the image equals the one rendered with room for every path."""
+@pytest.mark.parametrize("set_aside", ["1", "0"])
+def test_bpt_overflow_while_launches_are_in_flight(monkeypatch, set_aside):
+    """sub-paths that outgrow their slab share while two launches are in flight.  Default: the paths are set aside and traced again at 1024 vertices when the
+    batch's launches are done.  MI_BPT_SET_ASIDE=0: the shared counter does not say whose the overflow was — every trace not yet connected is redone one at a
+    time in slices at a larger share (bpt_launch).  Closed furnace at roulette 0.97 (sub-paths of a hundred vertices) with a slab budget that leaves 16
+    vertices: the image equals the one rendered with room for every path."""
     s = load_scene("TestCaseFurnace")
     pt = ma.PathTracing(s, beta=2.0, roulette=0.97)
-    monkeypatch.setenv("MI_BPT_FLIGHTS", "2")
+    monkeypatch.setenv("MI_BPT_FLIGHTS", "2"); monkeypatch.setenv("MI_BPT_SET_ASIDE", set_aside)
     ref = pt.bpt_render_rgbn(256, 256, spp=5, seed=11)
     monkeypatch.setenv("MI_BPT_SLAB_MB", "64")
     a = pt.bpt_render_rgbn(256, 256, spp=5, seed=11)

@@ -1815,7 +1815,11 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fe), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
     static const uint32_t n_cu = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return uint32_t(v); }();
-    uint32_t blocks = n_cu * waves * 4u / (kBlock / 64u);  // resident waves only: waves per SIMD x 4 SIMDs / waves per workgroup = workgroups per CU
+    // resident waves only, and not all of them: four workgroups per CU of the six the register budget allows (512 / 768 / 1024 / 1536 / 3072 workgroups: 139.5 / 134.6 /
+    // 133.2 / 138.0 / 140.1 ms LivingRoomLit, 48.3 / 47.3 / 46.6 / 49.9 / 50.7 ms MetalRings) — more paths per lane, and room for the kernels of the other launch in flight
+    (void)waves;
+    uint32_t blocks = n_cu * 4u;
+    if (const char* v = std::getenv("MI_BPT_PERSIST_BLOCKS")) { const long b = std::atol(v); if (b > 0) blocks = uint32_t(b); }  // measurement: fewer resident waves, more paths per lane
     if (blocks > grid.x) blocks = grid.x;
     e = hipMemsetAsync(w.step_count + 4, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;

@@ -50,5 +50,20 @@ for name in scenes:
             img_bad += 1; bad += 1
             print("IMAGE MISMATCH %s params %d: pixels %s counts %s" % (name, k, same, counts), flush=True)
 print("images: %d scenes x 3 parameter sets, %d mismatching frames" % (len(scenes), img_bad))
+# BPT frames through mi_bpt_render (r04: regenerating tracing kernels on the large models, two launches in flight, long paths set aside): 262 144 paths per scene —
+# enough for the launches in flight to engage — against the oracle's frames; the light-image splats and a pixel's frames add up in free FP64 order
+bpt_bad = 0
+for name in scenes:
+    s = ma.Scene.load(os.path.join(ROOT, "scenes", name + ".miscene"))
+    pb = ma.PathTracing(s, beta=2.0); ob = oracle.Oracle(s, beta=2.0)
+    a = pb.bpt_render_rgbn(256, 128, spp=8, seed=3); st = pb.last_stats
+    b = ob.bpt_render_rgbn(256, 128, spp=8, seed=3); so = ob.last_stats
+    same = (np.isclose(a, b, rtol=2e-6, atol=1e-12) | (np.isnan(a) & np.isnan(b))).all() and np.array_equal(a[..., 3], b[..., 3])
+    counts = (st.num_basic_rays, st.num_shadow_rays, st.numeric_errors) == (so.num_basic_rays, so.num_shadow_rays, so.numeric_errors)
+    cases += 1; paths += 256 * 128 * 8
+    if not (same and counts):
+        bpt_bad += 1; bad += 1
+        print("BPT IMAGE MISMATCH %s: pixels %s counts %s" % (name, same, counts), flush=True)
+print("BPT images: %d scenes, %d mismatching" % (len(scenes), bpt_bad))
 print("SUMMARY: %d scenes, %d cases, %d paths, %d cases with mismatches, %.0f s" % (len(scenes), cases, paths, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

@@ -19,6 +19,7 @@ struct BptState {
   uint32_t* over_ids;      // image mode, r04: a path whose sub-path outgrows max_vertices is set aside — its index (first + i) is appended here, it contributes nothing
   uint32_t* over_count;    // in this launch — and is traced again at the reference's capacity when the batch's launches are done.  nullptr: the launch counts
                            // the overflow (counters[15]) and the host redoes it in slices
+  uint32_t persist_hint;   // tracing stage of a scene read from HBM below 16 384 triangles: 0 / 1 = one lane per path, 2 = path regeneration (the host has seen >= 6.5 closest-hit rays per path)
   uint32_t async_total;    // 1: bpt_stage_trace leaves the item count's copy to the (pinned) host word in flight instead of waiting for it (launches overlapped on several streams)
   float4* slab;            // one-kernel form: [max_vertices][7][lanes] light sub-path vertices
   // staged form: path-major records (7 float4 per vertex), emission terms, per-path info, item offsets and values

@@ -1799,15 +1799,25 @@ hipError_t bpt_stage_trace(const RenderParams& p, const BptState& w, bool list, 
   }
   else if (p.wide_nodes == 1u) fn = list ? bpt_trace<true, 2> : bpt_trace<false, 2>;
   else fn = list ? bpt_trace<true, 1> : bpt_trace<false, 1>;
-  // r04: the two sub-paths as two kernels of resident waves with path regeneration (bpt_trace_light / bpt_trace_eye) where they pay — the models walked at six
-  // waves per SIMD (profiles/r04/ab_bpt_steps.txt #4: LivingRoomLit 205 -> 188 ms, MetalRings +-0; scenes in LDS 67 -> 99 ms: a launch holds four paths per resident
-  // lane and the longest sub-path, ~140 vertices, lasts as long as the rest of the kernel — twice with two kernels).  MI_BPT_PERSIST=0 / 1 forces one lane per path / this form.
-  bool persist = !lds_scene && p.sv.n_tris >= 16384u;
+  // r04: the two sub-paths as two kernels of resident waves with path regeneration (bpt_trace_light / bpt_trace_eye) where they pay (profiles/r04/ab_bpt_steps.txt #4,
+  // #7, #9): the models walked at six waves per SIMD (LivingRoomLit -23 %, MetalRings -13 %) and, of the smaller scenes read from HBM, those whose paths are long —
+  // every one with >= 6.7 closest-hit rays per path gains (-8 .. -37 %), every one with <= 6 loses (+5 .. +85 %: two kernels and a cursor for paths of two vertices);
+  // the host measures that on the launches it has finished (BptState::persist_hint).  Scenes in LDS keep one lane per path (67 -> 99 ms with regeneration).
+  // MI_BPT_PERSIST=0 / 1 forces one lane per path / this form.
+  bool persist = !lds_scene && (p.sv.n_tris >= 16384u || w.persist_hint == 2u);
   if (const char* v = std::getenv("MI_BPT_PERSIST")) persist = std::atoi(v) != 0 && !lds_scene;
   if (persist && w.step_count) {
     void (*fl)(const RenderParams, const BptState) = nullptr;
     void (*fe)(const RenderParams, const BptState) = nullptr;
     const uint32_t waves = 6u;
+    // register budget as for bpt_trace: six waves per SIMD (80 VGPRs) on the models whose walk is a chain of dependent fetches from L2 / HBM, four (128) on small
+    // trees — CornellBoxSpecular 103.0 -> 93.4 ms with regeneration at four, LivingRoomLit 134.9 (six) against 139.6 (four); MI_BPT_PERSIST_WAVES=4/6 forces one
+    bool four = p.sv.n_tris < 16384u;
+    if (const char* v = std::getenv("MI_BPT_PERSIST_WAVES")) four = std::atoi(v) == 4;
+    if (four) {
+      if (p.wide_nodes == 1u) { fl = list ? bpt_trace_light<true, 2, 4> : bpt_trace_light<false, 2, 4>; fe = list ? bpt_trace_eye<true, 2, 4> : bpt_trace_eye<false, 2, 4>; }
+      else { fl = list ? bpt_trace_light<true, 1, 4> : bpt_trace_light<false, 1, 4>; fe = list ? bpt_trace_eye<true, 1, 4> : bpt_trace_eye<false, 1, 4>; }
+    } else
     if (p.wide_nodes == 1u) { fl = list ? bpt_trace_light<true, 2, 6> : bpt_trace_light<false, 2, 6>; fe = list ? bpt_trace_eye<true, 2, 6> : bpt_trace_eye<false, 2, 6>; }
     else { fl = list ? bpt_trace_light<true, 1, 6> : bpt_trace_light<false, 1, 6>; fe = list ? bpt_trace_eye<true, 1, 6> : bpt_trace_eye<false, 1, 6>; }
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fl), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

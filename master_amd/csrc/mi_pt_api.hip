@@ -76,12 +76,13 @@ struct mi_pt_handle {
   static constexpr uint32_t kBptFlights = 4;
   struct BptFlight { hipStream_t stream = nullptr; hipEvent_t done = nullptr; float4* values = nullptr; size_t values_bytes = 0; };
   BptFlight bpt_flight[kBptFlights];
-  unsigned long long* bpt_pinned = nullptr;  // [kBptFlights][2]
+  unsigned long long* bpt_pinned = nullptr;  // [kBptFlights][8]: item count, overflow count, counters[0 .. 3] as the launch's trace saw them
   uint32_t* bpt_aside = nullptr; size_t bpt_aside_bytes = 0;  // [0] count, [16 ..] indices of the batch's paths set aside for the launch at 1024 vertices
   hipEvent_t bpt_fork = nullptr;             // h->stream -> the flights' streams
   float* bpt_eye = nullptr; size_t bpt_eye_bytes = 0;
   double* bpt_light = nullptr; size_t bpt_light_bytes = 0;
   float sphere[4] = {0, 0, 0, 0};
+  float bpt_rays_per_path = -1.0f;  // closest-hit rays per BPT path measured on this handle's finished launches (< 0: none yet): picks the tracing stage's form for small scenes
   uint32_t bpt_step_rounds = 0;  // rounds of the last BPT launch's tracing stage as uniform steps (0: the per-lane form ran)
   float sky_horizon[3] = {0, 0, 0}, sky_zenith[3] = {0, 0, 0};
   // frames in flight (mi_pt_render_frames_async / mi_pt_render_async / mi_pt_wait): a batch = the frames of ONE launch; per batch slot the
@@ -1609,8 +1610,13 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
       if (aside) HIP_TRY(hipMemsetAsync(h->bpt_aside, 0, 64, stream));
       for (uint64_t first = 0; first < lanes_total; first += per_launch) {
         w.first = uint32_t(first); w.lanes = uint32_t(lanes_total - first < per_launch ? lanes_total - first : per_launch);
+        w.persist_hint = h->bpt_rays_per_path < 0.0f ? 0u : (h->bpt_rays_per_path >= 6.5f ? 2u : 1u);
         rc = bpt_launch(h, p, w, false, stream);
         if (rc) return rc;
+        unsigned long long c4[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(c4, h->d_counters, sizeof c4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c4[3] >= 4096ull) h->bpt_rays_per_path = float(double(c4[0]) / double(c4[3]));
       }
       rc = flush_aside(f, w.frames, stream);
       if (rc) return rc;
@@ -1619,7 +1625,7 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
   } else {
     const mi::BptLaunchers bl = mi::bpt_launchers(p.features);
     const bool lds = use_lds_scene(h) && h->stack_fits_lds;
-    if (!h->bpt_pinned) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bpt_pinned), sizeof(unsigned long long) * 2 * mi_pt_handle::kBptFlights, hipHostMallocDefault));
+    if (!h->bpt_pinned) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bpt_pinned), sizeof(unsigned long long) * 8 * mi_pt_handle::kBptFlights, hipHostMallocDefault));
     if (!h->bpt_fork) HIP_TRY(hipEventCreateWithFlags(&h->bpt_fork, hipEventDisableTiming));
     for (uint32_t f = 0; f < flights; ++f) {
       auto& fl = h->bpt_flight[f];
@@ -1634,9 +1640,11 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
       auto& fl = h->bpt_flight[f];
       mi::BptState ws = state_of(f);
       ws.frame = frame; ws.frames = frames; ws.first = uint32_t(first); ws.lanes = lanes; ws.async_total = 1u;
-      uint32_t* total_word = reinterpret_cast<uint32_t*>(h->bpt_pinned + 2 * f);
+      ws.persist_hint = h->bpt_rays_per_path < 0.0f ? 0u : (h->bpt_rays_per_path >= 6.5f ? 2u : 1u);
+      uint32_t* total_word = reinterpret_cast<uint32_t*>(h->bpt_pinned + 8 * f);
       HIP_TRY(bl.trace(p, ws, false, lds, fl.stream, total_word));
-      HIP_TRY(hipMemcpyAsync(h->bpt_pinned + 2 * f + 1, h->d_counters + 15, sizeof(unsigned long long), hipMemcpyDeviceToHost, fl.stream));
+      HIP_TRY(hipMemcpyAsync(h->bpt_pinned + 8 * f + 1, h->d_counters + 15, sizeof(unsigned long long), hipMemcpyDeviceToHost, fl.stream));
+      HIP_TRY(hipMemcpyAsync(h->bpt_pinned + 8 * f + 2, h->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, fl.stream));  // rays and paths of the launches gathered so far
       cur[f] = ws; pending[f] = true;
       return MI_OK;
     };
@@ -1658,8 +1666,9 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
     auto finish = [&](uint32_t f) -> int {
       auto& fl = h->bpt_flight[f];
       HIP_TRY(hipStreamSynchronize(fl.stream));
-      if (h->bpt_pinned[2 * f + 1] != 0ull) return redo_pending();
-      const uint32_t items = *reinterpret_cast<const uint32_t*>(h->bpt_pinned + 2 * f);
+      if (h->bpt_pinned[8 * f + 1] != 0ull) return redo_pending();
+      const uint32_t items = *reinterpret_cast<const uint32_t*>(h->bpt_pinned + 8 * f);
+      if (h->bpt_pinned[8 * f + 5] >= 4096ull) h->bpt_rays_per_path = float(double(h->bpt_pinned[8 * f + 2]) / double(h->bpt_pinned[8 * f + 5]));
       mi::BptState& ws = cur[f];
       ws.dyn_vis = (!lds && items >= (1u << 19) && uint64_t(items) >= 2ull * ws.lanes) ? 1u : 0u;  // the rule of bpt_launch (2 M items for 1 M paths) per path
       if (const char* e = std::getenv("MI_BPT_DYN_VIS")) ws.dyn_vis = std::atoi(e) != 0 ? 1u : 0u;
@@ -1715,6 +1724,7 @@ int mi_bpt_render(mi_pt_handle* h, uint32_t camera_id, uint32_t width, uint32_t 
   HIP_TRY(hipMemcpyAsync(rgbn_sum, h->d_rgbn, np * 16, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   if (c[15]) return fail(MI_ERR_UNSUPPORTED, "BPT: " + std::to_string(c[15]) + " light sub-paths exceeded the vertex slab");
+  if (c[3] >= 4096ull) h->bpt_rays_per_path = float(double(c[0]) / double(c[3]));
   if (stats) {
     float t01 = 0.0f, t02 = 0.0f;
     HIP_TRY(hipEventElapsedTime(&t01, h->ev0, h->ev1));
